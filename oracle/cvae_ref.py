@@ -1,0 +1,426 @@
+"""CPU oracle for the cVAE hot path (TEST INFRASTRUCTURE, NOT THE PRODUCT).
+
+This file is a plain fp32 PyTorch-CPU restatement of the reference's conditional-VAE
+train step and deviation pass.  It exists so that the HIP path can be *checked*:
+only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it.  The product package never imports anything from
+``oracle/`` and fails loudly when its HIP library is missing.
+
+Pinning: the reference ships no tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself: ``oracle/gen_golden.py`` imports ``/root/reference/cVAE.py`` in the build
+container, drives its classes on seeded inputs with an explicit ``eps`` and
+commits the results as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against them.
+
+Every function cites the reference file:line it restates (paths relative to
+``/root/reference``).  Parameters are kept in a flat ``dict`` keyed by the
+reference's own ``state_dict`` names so weights interchange with it.
+
+All randomness is explicit: ``eps`` (the reparameterisation draw of
+``cVAE.py:418-421``) is always an argument.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+LEAKY_SLOPE = 0.01          # F.leaky_relu default, cVAE.py:167,203
+LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
+
+
+# ----------------------------------------------------------------------------------------
+# model description
+# ----------------------------------------------------------------------------------------
+@dataclass
+class Spec:
+    """Shape description of one cVAE_multimodal-family model.
+
+    Mirrors the constructor arguments of cVAE.py:1087-1116 (``input_dim_list``,
+    ``hidden_dim``, ``latent_dim``, ``c_dim``, ``modalities``, ``non_linear``).
+    """
+    input_dims: Sequence[int]
+    hidden: Sequence[int]
+    latent: int
+    c_dim: int
+    non_linear: bool = True
+    kind: str = "multimodal"      # "single" (cVAE), "multimodal", "regression", "endtoend"
+    classifier_layers: Sequence[int] = field(default_factory=list)   # endtoend only
+    num_classes: int = 2
+
+    @property
+    def M(self) -> int:
+        return len(self.input_dims)
+
+    def enc_sizes(self, m: int) -> List[int]:
+        # cVAE.py:153  layer_sizes_encoder = [input_dim + c_dim] + hidden_dims(+latent)
+        return [self.input_dims[m] + self.c_dim] + list(self.hidden) + [self.latent]
+
+    def dec_sizes(self, m: int) -> List[int]:
+        # cVAE.py:183-188  hidden_dims reversed, first entry + c_dim, then input_dim
+        hd = (list(self.hidden) + [self.latent])[::-1]
+        sizes = hd + [self.input_dims[m]]
+        sizes[0] = hd[0] + self.c_dim
+        return sizes
+
+
+def _enc_prefix(spec: Spec, m: int) -> str:
+    return "encoder." if spec.kind == "single" else f"encoder_list.{m}."
+
+
+def _dec_prefix(spec: Spec, m: int, bank: str = "") -> str:
+    if spec.kind == "single":
+        return "decoder."
+    if spec.kind == "endtoend":
+        return f"decoder_list_{bank}.{m}."
+    return f"decoder_list.{m}."
+
+
+def param_names(spec: Spec) -> List[str]:
+    """Names in the order the reference registers them (= ``state_dict()`` order).
+
+    cVAE_multimodal: alpha_m_list, encoder_list, decoder_list   (cVAE.py:1106-1108)
+    cVAE_multimodal_regression: encoder_list, decoder_list, alpha_m_list, regressor (cVAE.py:2230-2253)
+    cVAE (single): encoder, decoder (cVAE.py:406-407; the unused discriminator is not part of the path)
+    cVAE_multimodal_endtoend: encoder_list, decoder_list_health, decoder_list_disease, classifier (cVAE.py:2044-2054)
+    """
+    names: List[str] = []
+
+    def enc(m):
+        p = _enc_prefix(spec, m)
+        n_hidden = len(spec.hidden)
+        out = []
+        for i in range(n_hidden):
+            out += [f"{p}encoder_layers.{i}.weight", f"{p}encoder_layers.{i}.bias"]
+        out += [f"{p}enc_mean_layer.weight", f"{p}enc_mean_layer.bias",
+                f"{p}enc_logvar_layer.weight", f"{p}enc_logvar_layer.bias"]
+        return out
+
+    def dec(m, bank=""):
+        p = _dec_prefix(spec, m, bank)
+        n_hidden = len(spec.hidden)
+        out = [f"{p}logvar_out"]                    # registered first, cVAE.py:193-194 order of attributes
+        for i in range(n_hidden):
+            out += [f"{p}decoder_layers.{i}.weight", f"{p}decoder_layers.{i}.bias"]
+        out += [f"{p}decoder_mean_layer.weight", f"{p}decoder_mean_layer.bias"]
+        return out
+
+    if spec.kind == "single":
+        names += enc(0) + dec(0)
+    elif spec.kind == "multimodal":
+        names += [f"alpha_m_list.{m}" for m in range(spec.M)]
+        for m in range(spec.M):
+            names += enc(m)
+        for m in range(spec.M):
+            names += dec(m)
+    elif spec.kind == "regression":
+        for m in range(spec.M):
+            names += enc(m)
+        for m in range(spec.M):
+            names += dec(m)
+        names += [f"alpha_m_list.{m}" for m in range(spec.M)]
+        names += ["regressor.0.weight", "regressor.0.bias", "regressor.2.weight",
+                  "regressor.2.bias", "regressor.4.weight", "regressor.4.bias"]
+    elif spec.kind == "endtoend":
+        for m in range(spec.M):
+            names += enc(m)
+        for bank in ("health", "disease"):
+            for m in range(spec.M):
+                names += dec(m, bank)
+        sizes = [spec.latent] + list(spec.classifier_layers)
+        li = 0
+        for i in range(len(sizes) - 1):
+            names += [f"classifier.classifier.{li}.weight", f"classifier.classifier.{li}.bias",
+                      f"classifier.classifier.{li + 1}.weight", f"classifier.classifier.{li + 1}.bias"]
+            li += 4
+        names += [f"classifier.classifier.{li}.weight", f"classifier.classifier.{li}.bias"]
+    else:
+        raise ValueError(spec.kind)
+    return names
+
+
+def param_shapes(spec: Spec) -> Dict[str, tuple]:
+    shapes: Dict[str, tuple] = {}
+
+    def enc(m):
+        p = _enc_prefix(spec, m)
+        s = spec.enc_sizes(m)
+        for i in range(len(spec.hidden)):
+            shapes[f"{p}encoder_layers.{i}.weight"] = (s[i + 1], s[i])
+            shapes[f"{p}encoder_layers.{i}.bias"] = (s[i + 1],)
+        for h in ("enc_mean_layer", "enc_logvar_layer"):
+            shapes[f"{p}{h}.weight"] = (s[-1], s[-2])
+            shapes[f"{p}{h}.bias"] = (s[-1],)
+
+    def dec(m, bank=""):
+        p = _dec_prefix(spec, m, bank)
+        s = spec.dec_sizes(m)
+        shapes[f"{p}logvar_out"] = (1, spec.input_dims[m])
+        for i in range(len(spec.hidden)):
+            shapes[f"{p}decoder_layers.{i}.weight"] = (s[i + 1], s[i])
+            shapes[f"{p}decoder_layers.{i}.bias"] = (s[i + 1],)
+        shapes[f"{p}decoder_mean_layer.weight"] = (s[-1], s[-2])
+        shapes[f"{p}decoder_mean_layer.bias"] = (s[-1],)
+
+    for m in range(spec.M):
+        enc(m)
+        if spec.kind == "endtoend":
+            dec(m, "health")
+            dec(m, "disease")
+        else:
+            dec(m)
+    if spec.kind in ("multimodal", "regression"):
+        for m in range(spec.M):
+            shapes[f"alpha_m_list.{m}"] = (1,)
+    if spec.kind == "regression":
+        tot = sum(spec.input_dims)
+        shapes.update({"regressor.0.weight": (128, tot), "regressor.0.bias": (128,),
+                       "regressor.2.weight": (64, 128), "regressor.2.bias": (64,),
+                       "regressor.4.weight": (1, 64), "regressor.4.bias": (1,)})
+    if spec.kind == "endtoend":
+        sizes = [spec.latent] + list(spec.classifier_layers)
+        li = 0
+        for i in range(len(sizes) - 1):
+            shapes[f"classifier.classifier.{li}.weight"] = (sizes[i + 1], sizes[i])
+            shapes[f"classifier.classifier.{li}.bias"] = (sizes[i + 1],)
+            shapes[f"classifier.classifier.{li + 1}.weight"] = (sizes[i + 1],)   # BatchNorm1d gamma
+            shapes[f"classifier.classifier.{li + 1}.bias"] = (sizes[i + 1],)
+            li += 4
+        shapes[f"classifier.classifier.{li}.weight"] = (spec.num_classes, sizes[-1])
+        shapes[f"classifier.classifier.{li}.bias"] = (spec.num_classes,)
+    return {n: shapes[n] for n in param_names(spec)}
+
+
+def init_params(spec: Spec, seed: int = 42) -> Dict[str, torch.Tensor]:
+    """Reference init rule: nn.Linear default U(+-1/sqrt(fan_in)) for weight and bias
+    (cVAE.py:155-159,190-192), ``logvar_out`` = -3 (cVAE.py:179,193), ``alpha`` ~ N(0,1)
+    (cVAE.py:1106), BatchNorm gamma=1 / beta=0.  The draw ORDER differs from the
+    reference's constructor, so values are not the reference's for a given seed;
+    parity tests always load explicit weights."""
+    g = torch.Generator().manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in param_shapes(spec).items():
+        if name.endswith("logvar_out"):
+            out[name] = torch.full(shape, -3.0)
+        elif name.startswith("alpha_m_list"):
+            out[name] = torch.randn(shape, generator=g)
+        elif len(shape) == 2:
+            bound = 1.0 / math.sqrt(shape[1])
+            out[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        else:
+            # bias: needs fan_in of the matching weight
+            w = out.get(name[:-4] + "weight")
+            if w is not None and w.dim() == 2:
+                bound = 1.0 / math.sqrt(w.shape[1])
+                out[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            elif name.endswith("weight"):      # BatchNorm gamma
+                out[name] = torch.ones(shape)
+            else:                              # BatchNorm beta
+                out[name] = torch.zeros(shape)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# A1 / A2  encoder, decoder      (cVAE.py:140-172, 174-206)
+# ----------------------------------------------------------------------------------------
+def _act(h: torch.Tensor, non_linear: bool) -> torch.Tensor:
+    return torch.nn.functional.leaky_relu(h, LEAKY_SLOPE) if non_linear else h
+
+
+def encoder_fwd(P, spec: Spec, m: int, x: torch.Tensor, c: torch.Tensor):
+    """cVAE.py:161-172.  ``c`` may be int64 one-hot (train) or float; ``torch.cat``
+    promotes to float32 exactly as in the reference."""
+    p = _enc_prefix(spec, m)
+    h = torch.cat((x, c.to(x.dtype)), dim=1)
+    for i in range(len(spec.hidden)):
+        h = _act(torch.nn.functional.linear(h, P[f"{p}encoder_layers.{i}.weight"],
+                                            P[f"{p}encoder_layers.{i}.bias"]), spec.non_linear)
+    mu = torch.nn.functional.linear(h, P[f"{p}enc_mean_layer.weight"], P[f"{p}enc_mean_layer.bias"])
+    logvar = torch.nn.functional.linear(h, P[f"{p}enc_logvar_layer.weight"], P[f"{p}enc_logvar_layer.bias"])
+    return mu, logvar
+
+
+def decoder_fwd(P, spec: Spec, m: int, z: torch.Tensor, c: torch.Tensor, bank: str = ""):
+    """cVAE.py:197-206.  Returns (loc, scale) of the Normal; scale = exp(logvar_out)**0.5."""
+    p = _dec_prefix(spec, m, bank)
+    h = torch.cat((z, c.reshape(-1, spec.c_dim).to(z.dtype)), dim=1)
+    for i in range(len(spec.hidden)):
+        h = _act(torch.nn.functional.linear(h, P[f"{p}decoder_layers.{i}.weight"],
+                                            P[f"{p}decoder_layers.{i}.bias"]), spec.non_linear)
+    loc = torch.nn.functional.linear(h, P[f"{p}decoder_mean_layer.weight"], P[f"{p}decoder_mean_layer.bias"])
+    scale = P[f"{p}logvar_out"].exp().pow(0.5)
+    return loc, scale
+
+
+# ----------------------------------------------------------------------------------------
+# A3-A5  reparameterise / KL / LL
+# ----------------------------------------------------------------------------------------
+def reparameterise(mu, logvar, eps):
+    """cVAE.py:418-421 with the draw made explicit."""
+    return mu + eps * torch.exp(0.5 * logvar)
+
+
+def calc_kl(mu, logvar):
+    """cVAE.py:429-430 / 1138-1139."""
+    return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1).mean(0)
+
+
+def normal_log_prob(x, loc, scale):
+    """torch.distributions.Normal.log_prob: -(x-loc)^2/(2 scale^2) - log(scale) - log(sqrt(2 pi))."""
+    var = scale ** 2
+    return -((x - loc) ** 2) / (2 * var) - scale.log() - LOG_SQRT_2PI
+
+
+def compute_ll(x, loc, scale):
+    """cVAE.py:14-15: log_prob(x).sum(1, keepdims=True).mean(0) -> shape [1]."""
+    return normal_log_prob(x, loc, scale).sum(1, keepdim=True).mean(0)
+
+
+# ----------------------------------------------------------------------------------------
+# A7  expert fusion      (cVAE.py:986-998, 1000-1011, 1060-1083, 1144-1164)
+# ----------------------------------------------------------------------------------------
+def combine_latent(mus, variances, combine: str, alphas: Optional[Sequence[torch.Tensor]] = None,
+                   single_bypass: bool = True):
+    if single_bypass and mus.shape[0] == 1:           # cVAE.py:1146-1147
+        return mus[0], variances[0]
+    combine = combine.lower()
+    if combine == "poe":
+        T = 1.0 / variances
+        return torch.sum(mus * T, dim=0) / torch.sum(T, dim=0), 1.0 / torch.sum(T, dim=0)
+    if combine == "gpoe":
+        M = mus.shape[0]
+        a = torch.softmax(torch.stack([p for p in alphas]), dim=0).reshape(M, 1, 1)
+        mu = torch.sum(mus * a / variances, dim=0) / torch.sum(a / variances, dim=0)
+        return mu, 1 / torch.sum(a / variances, dim=0)
+    if combine == "moe":
+        w = 1.0 / mus.shape[0]
+        return torch.sum(mus * w, dim=0), torch.sum(variances * w, dim=0)
+    if combine == "mopoe":
+        T = 1.0 / variances
+        poe_mu = torch.sum(mus * T, dim=0) / torch.sum(T, dim=0)
+        poe_var = 1.0 / torch.sum(T, dim=0)
+        mus2 = torch.cat((mus, poe_mu.unsqueeze(0)), dim=0)
+        var2 = torch.cat((variances, poe_var.unsqueeze(0)), dim=0)
+        w = 1.0 / mus2.shape[0]
+        return torch.sum(mus2 * w, dim=0), torch.sum(var2 * w, dim=0)
+    raise ValueError("No such combination method")       # cVAE.py:1163
+
+
+# ----------------------------------------------------------------------------------------
+# A6 / A8 / A9  forward + loss
+# ----------------------------------------------------------------------------------------
+def forward_multimodal(P, spec: Spec, xes, cs, combine: str, eps):
+    """cVAE.py:1166-1182 (also cVAE.forward :435-443 when spec.kind == 'single')."""
+    if spec.kind == "single":
+        mu, logvar = encoder_fwd(P, spec, 0, xes[0], cs[0])
+        z = reparameterise(mu, logvar, eps)
+        loc, scale = decoder_fwd(P, spec, 0, z, cs[0])
+        return {"locs": [loc], "scales": [scale], "mu": mu, "logvar": logvar, "z": z,
+                "mus": mu.unsqueeze(0), "logvars": logvar.unsqueeze(0)}
+    enc = [encoder_fwd(P, spec, m, xes[m], cs[m]) for m in range(spec.M)]
+    mus = torch.stack([e[0] for e in enc])
+    logvars = torch.stack([e[1] for e in enc])
+    variances = torch.exp(logvars)
+    alphas = [P[f"alpha_m_list.{m}"] for m in range(spec.M)]
+    mu, var = combine_latent(mus, variances, combine, alphas)
+    logvar = torch.log(var)                               # exp -> log round trip, cVAE.py:1175-1178
+    z = reparameterise(mu, logvar, eps)
+    dec = [decoder_fwd(P, spec, m, z, cs[m]) for m in range(spec.M)]
+    return {"locs": [d[0] for d in dec], "scales": [d[1] for d in dec], "mu": mu, "logvar": logvar,
+            "z": z, "mus": mus, "logvars": logvars}
+
+
+def loss_multimodal(spec: Spec, xes, fwd):
+    """cVAE.py:1187-1196 (KL is added once PER MODALITY) / cVAE.loss_function :491-504."""
+    total = 0.0
+    kl_sum = 0.0
+    ll_sum = 0.0
+    lls = []
+    for m in range(spec.M):
+        kl = calc_kl(fwd["mu"], fwd["logvar"])
+        ll = compute_ll(xes[m], fwd["locs"][m], fwd["scales"][m])
+        total = total + (kl - ll)
+        kl_sum = kl_sum + kl
+        ll_sum = ll_sum + ll
+        lls.append(ll)
+    return {"total": total, "kl": kl_sum, "ll": ll_sum, "ll_m": lls}
+
+
+# ----------------------------------------------------------------------------------------
+# A10  Adam (torch.optim.Adam defaults, cVAE.py:1111-1116): lr=1e-4, betas=(0.9,0.999), eps=1e-8
+# ----------------------------------------------------------------------------------------
+class Adam:
+    """Hand-written restatement of torch.optim.Adam (no amsgrad, no weight decay)."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], names: Sequence[str], lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.names = list(names)
+        self.lr, self.b1, self.b2, self.eps = lr, betas[0], betas[1], eps
+        self.t = 0
+        self.m = {n: torch.zeros_like(P[n]) for n in self.names}
+        self.v = {n: torch.zeros_like(P[n]) for n in self.names}
+
+    @torch.no_grad()
+    def step(self, P, grads):
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        for n in self.names:
+            g = grads[n]
+            if g is None:
+                continue
+            self.m[n].mul_(self.b1).add_(g, alpha=1 - self.b1)
+            self.v[n].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (self.v[n].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            P[n].addcdiv_(self.m[n], denom, value=-self.lr / bc1)
+
+
+def optimizer_param_names(spec: Spec) -> List[str]:
+    """Which tensors the reference's optimizer owns (cVAE.py:1111-1116, 404, 2254-2260, 2057-2063)."""
+    return param_names(spec)
+
+
+def train_step(P, opt: Adam, spec: Spec, xes, cs, combine: str, eps):
+    """One iteration of the hot loop multimodal_kfold_train_cvae_supervised.py:193-199."""
+    leaves = {n: P[n].detach().clone().requires_grad_(True) for n in opt.names}
+    fwd = forward_multimodal(leaves, spec, xes, cs, combine, eps)
+    loss = loss_multimodal(spec, xes, fwd)
+    tot = loss["total"]
+    grads_list = torch.autograd.grad(tot.sum(), [leaves[n] for n in opt.names], allow_unused=True)
+    grads = {n: g for n, g in zip(opt.names, grads_list)}
+    opt.step(P, grads)
+    return ({k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss.items() if k != "ll_m"}
+            | {"ll_m": [l.detach() for l in loss["ll_m"]]}, grads, fwd)
+
+
+# ----------------------------------------------------------------------------------------
+# A11  deviation passes
+# ----------------------------------------------------------------------------------------
+@torch.no_grad()
+def deviation_unimodal(P, spec: Spec, m: int, x, c, eps):
+    """multimodal_kfold_train_cvae_supervised_regression.py:183-188: unimodal posterior,
+    SAMPLED z, per-ROI squared residual."""
+    mu, logvar = encoder_fwd(P, spec, m, x, c)
+    z = reparameterise(mu, logvar, eps)
+    loc, _ = decoder_fwd(P, spec, m, z, c)
+    return (x - loc) ** 2, loc
+
+
+@torch.no_grad()
+def pred_recon(P, spec: Spec, xes, c, combine: str, eps):
+    """cVAE.py:1198-1208 (joint latent, sampled z; covariates cast to long there)."""
+    cs = [c for _ in range(spec.M)]
+    fwd = forward_multimodal(P, spec, xes, cs, combine, eps)
+    return [l for l in fwd["locs"]]
+
+
+def reconstruction_deviation(x, x_pred):
+    """utils_vae.py:147-148 / cVAE.py:1210-1211: sum_d (x - x_pred)^2 / D per subject."""
+    return ((x - x_pred) ** 2).sum(1) / x.shape[1]
+
+
+def reconstruction_deviation_roi(x, x_pred):
+    """utils_vae.py:151-152."""
+    return (x - x_pred) ** 2

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (build container only).
+
+Imports ``/root/reference/cVAE.py`` (read-only mount, never copied), drives its classes on
+seeded synthetic inputs with an explicit reparameterisation draw, and writes
+``tests/golden/*.npz``.  The fixtures hold data only: inputs, weights keyed by the
+reference's ``state_dict`` names, and expected outputs.  The reference itself never travels
+to the GPU box; tests compare oracle <-> golden here and HIP <-> oracle/golden there.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+from contextlib import contextmanager
+from pathlib import Path
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    import cVAE as ref  # noqa
+    return ref
+
+
+@contextmanager
+def fixed_eps(eps_list):
+    """Make every ``torch.randn_like`` call inside the reference return the next preset draw."""
+    it = iter(eps_list)
+    orig = torch.randn_like
+
+    def fake(t, *a, **k):
+        e = next(it)
+        assert e.shape == t.shape, (e.shape, t.shape)
+        return e.clone()
+
+    torch.randn_like = fake
+    try:
+        yield
+    finally:
+        torch.randn_like = orig
+
+
+def onehot_cov(g, B, c_dim):
+    """27 age bins + 2 sex bins when c_dim == 29, else split c_dim-2 / 2 the same way."""
+    na = c_dim - 2
+    a = torch.randint(0, na, (B,), generator=g)
+    s = torch.randint(0, 2, (B,), generator=g)
+    c = torch.zeros(B, c_dim)
+    c[torch.arange(B), a] = 1
+    c[torch.arange(B), na + s] = 1
+    return c
+
+
+def sd_np(model, prefix="w:"):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def grads_np(model, prefix="g:"):
+    out = {}
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out[prefix + k] = p.grad.detach().cpu().numpy().copy()
+    return out
+
+
+def adam_np(opt, model, prefix):
+    out = {}
+    name_of = {id(p): k for k, p in model.named_parameters()}
+    for p, st in opt.state.items():
+        k = name_of[id(p)]
+        out[f"{prefix}m:{k}"] = st["exp_avg"].detach().numpy().copy()
+        out[f"{prefix}v:{k}"] = st["exp_avg_sq"].detach().numpy().copy()
+    return out
+
+
+def case_multimodal(ref, name, dims, c_dim, hidden, Z, B, combine, n_steps, seed, int_cov=True, store_steps=(1,)):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    M = len(dims)
+    model = ref.cVAE_multimodal(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
+                                learning_rate=1e-4, modalities=M, non_linear=True)
+    out = {"meta": np.array([M, c_dim, Z, B, n_steps]), "dims": np.array(dims), "hidden": np.array(hidden),
+           "combine": np.array(combine)}
+    out.update(sd_np(model, "w0:"))
+    xs = [torch.randn(n_steps, B, d, generator=g) * 1.3 + 0.1 for d in dims]
+    c = torch.stack([onehot_cov(g, B, c_dim) for _ in range(n_steps)])
+    eps = torch.randn(n_steps, B, Z, generator=g)
+    for m in range(M):
+        out[f"x{m}"] = xs[m].numpy()
+    out["c"] = c.numpy()
+    out["eps"] = eps.numpy()
+    for s in range(n_steps):
+        xes = [xs[m][s] for m in range(M)]
+        cc = c[s].long() if int_cov else c[s]        # MyDataset_labels casts one-hot to int64 (utils_vae.py:24)
+        cs = [cc for _ in range(M)]
+        with fixed_eps([eps[s]]):
+            fwd = model.forward_multimodal(xes, cs, combine)
+        loss = model.loss_function_multimodal(xes, fwd)
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        if s == 0:
+            out["mu"] = fwd["mu_multimodal"].detach().numpy().copy()
+            out["logvar"] = fwd["logvar_multimodal"].detach().numpy().copy()
+            for m in range(M):
+                out[f"loc{m}"] = fwd["x_recons"][m].loc.detach().numpy().copy()
+                out[f"scale{m}"] = fwd["x_recons"][m].scale.detach().numpy().copy()
+            out.update(grads_np(model, "g0:"))
+        out[f"loss{s}"] = np.array([float(loss["total"]), float(loss["kl"]), float(loss["ll"])], dtype=np.float64)
+        model.optimizer1.step()
+        if (s + 1) in store_steps:
+            out.update(sd_np(model, f"w{s + 1}:"))
+            out.update(adam_np(model.optimizer1, model, f"a{s + 1}:"))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name, {k: float(out[k][0]) for k in out if k.startswith("loss")})
+
+
+def case_single(ref, name, D, c_dim, hidden, Z, B, seed):
+    """class cVAE (cVAE.py:391-562): forward + loss_function + pred_recon/pred_latent."""
+    import pandas as pd
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    model = ref.cVAE(input_dim=D, hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim, learning_rate=1e-4,
+                     non_linear=True)
+    x = torch.randn(B, D, generator=g)
+    c = onehot_cov(g, B, c_dim)
+    eps = torch.randn(B, Z, generator=g)
+    out = {"meta": np.array([1, c_dim, Z, B, 1]), "dims": np.array([D]), "hidden": np.array(hidden)}
+    out.update({k: v for k, v in sd_np(model, "w0:").items() if "discriminator" not in k})
+    with fixed_eps([eps]):
+        fwd = model.forward(x, c.long())
+    loss = model.loss_function(x, fwd)
+    model.optimizer1.zero_grad()
+    loss["total"].backward()
+    out.update({k: v for k, v in grads_np(model, "g0:").items() if "discriminator" not in k})
+    out.update({"x0": x.numpy(), "c": c.numpy(), "eps": eps.numpy(),
+                "mu": fwd["mu"].detach().numpy(), "logvar": fwd["logvar"].detach().numpy(),
+                "loc0": fwd["x_recon"].loc.detach().numpy(), "scale0": fwd["x_recon"].scale.detach().numpy(),
+                "loss0": np.array([float(loss["total"]), float(loss["kl"]), float(loss["ll"])])})
+    model.optimizer1.step()
+    out.update({k: v for k, v in sd_np(model, "w1:").items() if "discriminator" not in k})
+    # pred_recon uses mu (no draw) for the single-modality class, cVAE.py:547-553
+    xdf = pd.DataFrame(x.numpy())
+    out["pred_recon"] = model.pred_recon(xdf, c.long().numpy(), torch.device("cpu"))
+    lat, latvar = model.pred_latent(xdf, c.long().numpy(), torch.device("cpu"))
+    out["pred_latent"] = lat
+    out["pred_latent_var"] = latvar
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name)
+
+
+def case_deviation(ref, name, dims, c_dim, hidden, Z, N, combine, seed):
+    """(i) regression-script unimodal (x - x_hat)^2 with raw float covariates
+    (multimodal_kfold_train_cvae_supervised_regression.py:183-188);
+    (ii) pred_recon + reconstruction_deviation_multimodal (cVAE.py:1198-1211)."""
+    import pandas as pd
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    M = len(dims)
+    model = ref.cVAE_multimodal(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
+                                learning_rate=1e-4, modalities=M, non_linear=True)
+    out = {"meta": np.array([M, c_dim, Z, N, 0]), "dims": np.array(dims), "hidden": np.array(hidden),
+           "combine": np.array(combine)}
+    out.update(sd_np(model, "w0:"))
+    xs = [torch.randn(N, d, generator=g) for d in dims]
+    c_onehot = onehot_cov(g, N, c_dim)
+    c_raw = torch.rand(N, c_dim, generator=g) * 3.0           # raw-float covariates, as in the regression script
+    eps_uni = torch.randn(M, N, Z, generator=g)
+    eps_joint = torch.randn(N, Z, generator=g)
+    for m in range(M):
+        out[f"x{m}"] = xs[m].numpy()
+        with torch.no_grad(), fixed_eps([eps_uni[m]]):
+            mu, logvar = model.encode(xs[m], c_raw, m)
+            z = model.reparameterise(mu, logvar)
+            loc = model.decode(z, c_raw, m).loc
+            out[f"uni_dev{m}"] = ((xs[m] - loc) ** 2).numpy()
+            out[f"uni_loc{m}"] = loc.numpy()
+    dfs = [pd.DataFrame(x.numpy()) for x in xs]
+    with fixed_eps([eps_joint]):
+        preds = model.pred_recon(dfs, c_onehot.numpy(), torch.device("cpu"), combine)
+    devs = model.reconstruction_deviation_multimodal([d.values for d in dfs], preds)
+    for m in range(M):
+        out[f"joint_pred{m}"] = preds[m]
+        out[f"joint_dev{m}"] = np.asarray(devs[m])
+    out.update({"c_onehot": c_onehot.numpy(), "c_raw": c_raw.numpy(), "eps_uni": eps_uni.numpy(),
+                "eps_joint": eps_joint.numpy()})
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name)
+
+
+def case_csv_headers(name):
+    """G7/G8: layout facts of the committed CSV artefacts (first line + IID column only, plus a
+    known-answer slice of one (x, x_hat, err_roi, err) quintuple)."""
+    import pandas as pd
+    out = {}
+    p = Path(REF) / "regression_outputs" / "deviation_fold_0_T1w_sMRI_roiwise.csv"
+    df = pd.read_csv(p)
+    out["roiwise_header"] = np.array(list(df.columns))
+    out["roiwise_iid"] = df["IID"].to_numpy()
+    with open(p) as f:
+        f.readline()
+        out["roiwise_row0_text"] = np.array(f.readline().strip())
+    out["roiwise_row0_vals"] = df.iloc[0, 1:].to_numpy(dtype=np.float32)
+    base = Path(REF) / "deviation" / "supervised_cvae" / "ADNI" / "UCA-gPoE" / "av45"
+    nrm = pd.read_csv(base / "normalized_av45.csv")
+    rec = pd.read_csv(base / "reconstruction_av45.csv")
+    err_roi = pd.read_csv(base / "reconstruction_error_roi_av45.csv")
+    err = pd.read_csv(base / "reconstruction_error_av45.csv")
+    fi = pd.read_csv(base / "deviation_as_feature_importance_av45.csv")
+    n = 64
+    meta_cols = ["participant_id", "DIA", "AGE", "PTGENDER"]
+    roi_cols = [c for c in nrm.columns if c not in meta_cols]
+    out["adni_cols"] = np.array(list(nrm.columns))
+    out["adni_fi_cols"] = np.array(list(fi.columns))
+    out["adni_err_cols"] = np.array(list(err.columns))
+    out["adni_x"] = nrm[roi_cols].to_numpy()[:n]
+    out["adni_xhat"] = rec[roi_cols].to_numpy()[:n]
+    out["adni_err_roi"] = err_roi[roi_cols].to_numpy()[:n]
+    out["adni_err"] = err["Reconstruction error"].to_numpy()[:n]
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name)
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    ref = _import_reference()
+    # small shapes: every combiner, ragged rows, float vs int covariates
+    for comb in ("poe", "gpoe", "moe", "mopoe"):
+        case_multimodal(ref, f"mm3_{comb}", (23, 17, 29), 7, (24, 16), 6, 19, comb, 3, seed=100, store_steps=(1, 3))
+    case_multimodal(ref, "mm1_small", (37,), 7, (24, 16), 6, 19, "gpoe", 5, seed=101, store_steps=(1, 5))
+    case_multimodal(ref, "mm4_uca_gpoe", (12, 11, 13, 36), 7, (24, 16), 6, 32, "gpoe", 2, seed=102, store_steps=(2,))
+    case_multimodal(ref, "mm1_h1", (21,), 4, (20,), 5, 16, "poe", 2, seed=103, store_steps=(2,))
+    case_multimodal(ref, "mm2_z64", (40, 33), 29, (48, 40), 64, 48, "poe", 2, seed=104, store_steps=(2,))
+    # BASELINE config A: D=379, c=29, H=[110,110], Z=10, B=256 (one step; full-size grads)
+    case_multimodal(ref, "cfgA_T1w", (379,), 29, (110, 110), 10, 256, "gpoe", 2, seed=7, store_steps=(2,))
+    # ragged tail of the real HCPimage size (83 rows)
+    case_multimodal(ref, "cfgA_T1w_tail83", (379,), 29, (110, 110), 10, 83, "gpoe", 1, seed=8, store_steps=())
+    case_single(ref, "single_small", 37, 7, (24, 16), 6, 19, seed=105)
+    case_deviation(ref, "dev_small", (23, 17, 29), 5, (24, 16), 6, 40, "gpoe", seed=106)
+    case_csv_headers("csv_layouts")
+
+
+if __name__ == "__main__":
+    main()
