@@ -1,0 +1,159 @@
+/*
+ * nmhip.h -- C ABI of libnmhip.so: the MI355X (gfx950) conditional-VAE hot path.
+ *
+ * The reference (soz223/multi_modal_normative_modeling) has no FFI layer; the boundary this
+ * library sits behind is the Python class surface of cVAE.py.  Each entry point below names
+ * the reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   nm_train_steps   forward_multimodal + loss_function_multimodal + backward + optimizer1.step()
+ *                    i.e. the hot loop multimodal_kfold_train_cvae_supervised.py:177-199 over
+ *                    cVAE.py:1166-1196 (and cVAE.forward/loss_function :435-443, :491-504 for M = 1)
+ *   nm_forward       forward only: cVAE_multimodal.forward_multimodal / pred_recon (cVAE.py:1166-1182,
+ *                    :1198-1208), the unimodal encode->reparameterise->decode deviation pass of
+ *                    multimodal_kfold_train_cvae_supervised_regression.py:183-188, and
+ *                    (x - x_hat)^2 of utils_vae.py:151-152
+ *   nm_grads         forward + loss + backward, gradients written out instead of applied
+ *                    (loss['total'].backward(), multimodal_kfold_train_cvae_supervised.py:198)
+ *   nm_adam_step     torch.optim.Adam.step() as configured at cVAE.py:1111-1116
+ *   nm_pack_table    the per-batch torch.cat((x, c), dim=1) of cVAE.py:163 done once per table
+ *
+ * Conventions: plain C, raw DEVICE pointers (tensor.data_ptr()), explicit sizes, a hipStream_t
+ * passed as void*, int status return (0 ok, <0 argument error, >0 hipError_t).  Nothing here
+ * allocates memory the caller does not own: every buffer, including the workspace, is passed
+ * in.  Functions are re-entrant per (device, stream).
+ */
+#ifndef NMHIP_H
+#define NMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_MAX_MOD 4     /* experts / modalities per model (SM: 1, SE: 3, UCA: 4) */
+#define NM_MAX_HID 3     /* hidden layers per encoder / decoder stack            */
+#define NM_BATCH   256   /* rows per workgroup tile (= reference batch size)      */
+#define NM_MAX_WIDTH 127 /* max hidden width, and max latent + c_dim             */
+#define NM_MAX_LATENT 64
+
+/* expert fusion, cVAE.py:1144-1164 */
+enum { NM_COMBINE_POE = 0, NM_COMBINE_GPOE = 1, NM_COMBINE_MOE = 2, NM_COMBINE_MOPOE = 3 };
+
+/* mode flags of nm_launch */
+enum {
+  NM_F_BACKWARD = 1,   /* run the backward pass                                        */
+  NM_F_ADAM     = 2,   /* apply Adam inside the weight-gradient epilogues             */
+  NM_F_GRADS    = 4,   /* store gradients to job.grads (parameter layout)             */
+  NM_F_EXPORT   = 8    /* store mu / logvar / z / loc / squared residual per row      */
+};
+
+/* One modality (expert) of a model: its ROI table and where its tensors live inside the
+ * job's flat fp32 parameter buffer.  Offsets are in floats; tensors keep the reference's own
+ * shapes and row-major [out][in] layout (nn.Linear), so a state_dict copies in and out. */
+typedef struct nm_modality {
+  int32_t D;              /* ROI features of this modality                               */
+  int32_t Kx;             /* row pitch of xb in elements: multiple of 32, >= D + C + 1   */
+  const float*    x_f32;  /* [rows_alloc][D]   fp32 inputs (residual / NLL side)         */
+  const uint16_t* xb;     /* [rows_alloc][Kx]  bf16: x | c | 1 | 0...   (MFMA operand)   */
+  int64_t enc_w[NM_MAX_HID], enc_b[NM_MAX_HID];   /* encoder_layers.{i}.weight/.bias      */
+  int64_t mu_w, mu_b, lv_w, lv_b;                 /* enc_mean_layer / enc_logvar_layer    */
+  int64_t logvar_out;                             /* decoder logvar_out [1][D]            */
+  int64_t dec_w[NM_MAX_HID], dec_b[NM_MAX_HID];   /* decoder_layers.{i}                   */
+  int64_t out_w, out_b;                           /* decoder_mean_layer                   */
+  int64_t alpha;                                  /* alpha_m_list.{m} or -1               */
+  /* optional per-row exports (NM_F_EXPORT), indexed by absolute table row; may be NULL */
+  float* out_loc;         /* [rows_alloc][D]  decoder mean x_hat                         */
+  float* out_sqerr;       /* [rows_alloc][D]  (x - x_hat)^2                              */
+  float* out_rowdev;      /* [rows_alloc]     sum_d (x - x_hat)^2 / D                    */
+} nm_modality_t;
+
+/* One independent model (a (fold, procedure) cell of the sweep). */
+typedef struct nm_job {
+  int32_t M;              /* modalities                                                  */
+  int32_t C;              /* covariate width c_dim                                       */
+  int32_t L;              /* hidden layers                                               */
+  int32_t Z;              /* latent width                                                */
+  int32_t H[NM_MAX_HID];  /* encoder hidden widths; the decoder uses them reversed       */
+  int32_t combine;        /* NM_COMBINE_*                                                */
+  int32_t single_bypass;  /* 1: M == 1 skips fusion (cVAE.py:1146-1147)                  */
+  int32_t n_rows;         /* valid rows in the tables                                    */
+  int32_t non_linear;     /* 1: LeakyReLU(0.01) between layers (cVAE.py:166-167)         */
+  int32_t loss_cap;       /* rows of loss_log; step s writes row s % loss_cap            */
+  int32_t eps_cap;        /* steps held by eps; step s reads block s % eps_cap           */
+  float   lr, beta1, beta2, adam_eps;
+  double  beta1_pow, beta2_pow;   /* beta^t for t = steps already taken (host, double)   */
+  float   kl_weight;      /* d total / d KL   (= M for cVAE_multimodal, cVAE.py:1189-1195) */
+  float   ll_weight;      /* d total / d (-LL_m)                                          */
+  float*  params;         /* flat fp32 parameters                                        */
+  float*  adam_m;         /* exp_avg                                                     */
+  float*  adam_v;         /* exp_avg_sq                                                  */
+  float*  grads;          /* NM_F_GRADS target, same layout as params (may be NULL)      */
+  const float* eps;       /* [eps_cap][NM_BATCH][Z] reparameterisation draws, or NULL
+                             to use the in-kernel counter-based generator              */
+  uint64_t seed;          /* generator key when eps == NULL                              */
+  float*  loss_log;       /* [loss_cap][NM_LOSS_STRIDE] (may be NULL)                    */
+  void*   workspace;      /* nm_workspace_bytes() per concurrently running tile          */
+  int64_t workspace_stride; /* bytes between the workspaces of consecutive tiles        */
+  float*  out_mu;         /* NM_F_EXPORT: [rows_alloc][Z] joint mu      (may be NULL)    */
+  float*  out_logvar;     /* NM_F_EXPORT: [rows_alloc][Z] joint logvar  (may be NULL)    */
+  float*  out_z;          /* NM_F_EXPORT: [rows_alloc][Z] sampled z     (may be NULL)    */
+  nm_modality_t mod[NM_MAX_MOD];
+} nm_job_t;
+
+/* loss_log row: total, kl (weighted sum as the reference reports it), ll (sum over m), then ll_m */
+#define NM_LOSS_STRIDE 8
+#define NM_LOSS_TOTAL 0
+#define NM_LOSS_KL    1
+#define NM_LOSS_LL    2
+#define NM_LOSS_LL_M  3
+
+/* Bytes of workspace one tile of a job needs (host-side helper, no device access). */
+int64_t nm_workspace_bytes(const nm_job_t* job_host);
+
+/* Validate shapes against the kernel's limits. 0 ok, negative = which limit. */
+int nm_validate_job(const nm_job_t* job_host);
+
+/* Core launch.  jobs_dev: device array of n_jobs descriptors.  Workgroup (j, t) runs job j
+ * over steps [step0 + t*steps_per_tile, +steps_per_tile); step s uses table rows
+ * [b*256, min(n_rows, (b+1)*256)) with b = s mod ceil(n_rows/256), exactly the batches of a
+ * shuffle=False DataLoader (multimodal_kfold_train_cvae_supervised.py:131).
+ * Training: n_tiles = 1 and steps_per_tile = number of steps (persistent per job).
+ * Inference: one tile per 256 rows. */
+int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles,
+              int flags, void* stream);
+
+/* Convenience wrappers over nm_launch (same status convention). */
+int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream);
+int nm_grads(const nm_job_t* jobs_dev, int n_jobs, int step, void* stream);
+int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream);
+
+/* Stand-alone flat Adam (used by the eager API path).  t is the 1-based step count. */
+int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                 float lr, float beta1, float beta2, float eps, int64_t t, void* stream);
+
+/* Build the bf16 operand table xb[rows_alloc][Kx] = x | c | 1 | 0 from fp32 x [n_rows][D] and
+ * fp32 c [n_rows][C]; rows >= n_rows are zero-filled.  Also zero-pads x_f32_out if given. */
+int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx,
+                  uint16_t* xb, float* x_f32_out, void* stream);
+
+/* Debug / unit-test entry: C[M][N] = A[M][K] * B[N][K]^T through the kernel's own fragment
+ * loaders.  mode 0: A row-major via LDS, B fp32 weights (forward form); mode 1: dgrad form
+ * (B read transposed); mode 2: wgrad form, both operands read transposed from LDS with
+ * ds_read_b64_tr_b16; mode 3: same with the scalar reference loader. */
+int nm_test_gemm(int mode, const float* A, const float* B, float* Cout, int M, int N, int K, void* stream);
+
+/* sizeof(nm_job_t), sizeof(nm_modality_t): lets a binding check its struct mirror. */
+int nm_abi_sizes(int64_t* sizeof_job, int64_t* sizeof_modality);
+
+/* nm_launch with the scalar transposing LDS loader (validates ds_read_b64_tr_b16). */
+int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles,
+                        int flags, void* stream);
+
+const char* nm_status_string(int status);
+int nm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMHIP_H */

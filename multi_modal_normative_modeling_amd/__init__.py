@@ -1,0 +1,7 @@
+"""MI355X-native conditional-VAE normative-modeling hot path (HIP kernels behind the
+reference's own cVAE class surface).  See DESIGN.md."""
+from . import _lib
+from .layout import ModelSpec, ParamLayout
+from .engine import Table, Job, JobSet, adam_step
+
+__all__ = ["ModelSpec", "ParamLayout", "Table", "Job", "JobSet", "adam_step", "_lib"]

@@ -1,0 +1,113 @@
+"""ctypes binding of libnmhip.so (include/nmhip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, the
+caller gets an exception.  ``oracle/`` is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+NM_MAX_MOD = 4
+NM_MAX_HID = 3
+NM_BATCH = 256
+NM_MAX_WIDTH = 127
+NM_MAX_LATENT = 64
+NM_LOSS_STRIDE = 8
+
+NM_COMBINE = {"poe": 0, "gpoe": 1, "moe": 2, "mopoe": 3}
+
+NM_F_BACKWARD = 1
+NM_F_ADAM = 2
+NM_F_GRADS = 4
+NM_F_EXPORT = 8
+
+LIB_NAME = "libnmhip.so"
+LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+
+
+class NmModality(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32), ("Kx", C.c_int32),
+        ("x_f32", C.c_void_p), ("xb", C.c_void_p),
+        ("enc_w", C.c_int64 * NM_MAX_HID), ("enc_b", C.c_int64 * NM_MAX_HID),
+        ("mu_w", C.c_int64), ("mu_b", C.c_int64), ("lv_w", C.c_int64), ("lv_b", C.c_int64),
+        ("logvar_out", C.c_int64),
+        ("dec_w", C.c_int64 * NM_MAX_HID), ("dec_b", C.c_int64 * NM_MAX_HID),
+        ("out_w", C.c_int64), ("out_b", C.c_int64),
+        ("alpha", C.c_int64),
+        ("out_loc", C.c_void_p), ("out_sqerr", C.c_void_p), ("out_rowdev", C.c_void_p),
+    ]
+
+
+class NmJob(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("Z", C.c_int32),
+        ("H", C.c_int32 * NM_MAX_HID),
+        ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32),
+        ("loss_cap", C.c_int32), ("eps_cap", C.c_int32),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("beta1_pow", C.c_double), ("beta2_pow", C.c_double),
+        ("kl_weight", C.c_float), ("ll_weight", C.c_float),
+        ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("grads", C.c_void_p),
+        ("eps", C.c_void_p), ("seed", C.c_uint64),
+        ("loss_log", C.c_void_p), ("workspace", C.c_void_p), ("workspace_stride", C.c_int64),
+        ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p),
+        ("mod", NmModality * NM_MAX_MOD),
+    ]
+
+
+class NmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libnmhip.so from the package directory; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NmError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    lib.nm_version.restype = C.c_int
+    lib.nm_status_string.restype = C.c_char_p
+    lib.nm_status_string.argtypes = [C.c_int]
+    lib.nm_abi_sizes.argtypes = [C.POINTER(i64), C.POINTER(i64)]
+    lib.nm_workspace_bytes.restype = i64
+    lib.nm_workspace_bytes.argtypes = [C.POINTER(NmJob)]
+    lib.nm_validate_job.argtypes = [C.POINTER(NmJob)]
+    for name in ("nm_launch", "nm_launch_scalar_tr"):
+        getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
+    lib.nm_grads.argtypes = [vp, i32, i32, vp]
+    lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
+    lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
+    lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
+    sj, sm = i64(0), i64(0)
+    lib.nm_abi_sizes(C.byref(sj), C.byref(sm))
+    if sj.value != C.sizeof(NmJob) or sm.value != C.sizeof(NmModality):
+        raise NmError(f"ABI mismatch: C sizeof(nm_job_t)={sj.value}, sizeof(nm_modality_t)={sm.value}; "
+                      f"ctypes {C.sizeof(NmJob)}, {C.sizeof(NmModality)}")
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
+    "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
+    "nm_test_gemm",
+]
+
+
+def check(status: int, what: str = "nmhip"):
+    if status != 0:
+        msg = load().nm_status_string(status).decode()
+        raise NmError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,1262 @@
+// nmhip.hip -- conditional-VAE train step / forward / deviation pass for MI355X (gfx950, CDNA4).
+//
+// One 512-thread workgroup (8 wavefronts of 64 lanes, two per SIMD) owns one model ("job") and
+// runs whole train steps for it: encoder MLPs -> expert fusion -> reparameterisation -> decoder
+// MLPs -> Gaussian NLL + KL -> backward -> Adam, with no inter-workgroup communication.  The
+// sweep fills the chip with independent jobs (one workgroup per CU), see DESIGN.md.
+//
+// Data placement per workgroup
+//   LDS  P [256][136] bf16 : the running activation / delta of the layer chain (updated in place)
+//        Q [256][136] bf16 : the other operand of the current layer (saved activation, staged
+//                            x-chunk, or delta chunk of the decoder output layer)
+//   HBM/L2  fp32 parameters + Adam moments in the reference's own tensor layout; weights are read
+//           straight into MFMA B-fragments (fp32 -> bf16 in registers), each element once per
+//           pass; Adam runs in the weight-gradient epilogue on the accumulator tile.
+//   workspace (L2-resident): fp32 latent statistics, bf16 activations saved for backward.
+//
+// Every contraction is a v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The three GEMM forms:
+//   forward  out[r][n] = sum_k P[r][k] W[n][k]        A = ds_read_b128 of P rows, B = W rows
+//   dgrad    din[r][k] = sum_n P[r][n] W[n][k]        A = ds_read_b128 of P rows, B = W columns
+//   wgrad    dW[n][k]  = sum_r P[r][n] Q[r][k]        A, B = ds_read_b64_tr_b16 (transposing read)
+//
+// Reference semantics restated here (paths relative to the reference checkout):
+//   Encoder/Decoder            cVAE.py:140-206        expert fusion  cVAE.py:986-1083, 1144-1164
+//   reparameterise / KL / LL   cVAE.py:14-15, 1130-1142
+//   forward_multimodal / loss  cVAE.py:1166-1196      Adam           cVAE.py:1111-1116
+//   deviation (x - x_hat)^2    multimodal_kfold_train_cvae_supervised_regression.py:183-188
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "nmhip.h"
+
+namespace {
+
+constexpr int WG = 512;          // threads per workgroup
+constexpr int NWAVES = 8;
+constexpr int ROWS = NM_BATCH;   // 256 rows per tile
+constexpr int PW = 128;          // padded feature width held in P/Q
+constexpr int LDP = 136;         // P/Q row pitch (elements): +8 breaks the 256-B bank period
+constexpr int LDX = 72;          // row pitch of a staged 64-column x chunk inside Q
+constexpr int XCH = 64;          // columns per staged x chunk
+constexpr float SLOPE = 0.01f;   // F.leaky_relu default (cVAE.py:167,203)
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+struct Ctx {
+  const nm_job_t* job;
+  __bf16* P;
+  __bf16* Q;
+  float* red;        // [64] reduction scratch
+  float* colacc;     // [128] per-column accumulators
+  float* rowacc;     // [256] per-row accumulators
+  int tid, lane, wave, wm, wn, g, c16;
+  int row0;          // first table row of this tile
+  int nrows;         // valid rows in this tile (<= 256)
+  int flags;
+  float inv_b;       // 1 / nrows
+  // Adam scalars of the current step
+  float step_size;   // lr / (1 - beta1^t)
+  float inv_bc2_sqrt;
+  char* ws;          // workspace of this tile
+};
+
+__host__ __device__ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline int wpad(int n) { return rup(n + 1, 32); }   // width incl. the ones column
+
+// ---- workspace layout (shared by host and device) ------------------------------------------
+struct WsLayout {
+  int64_t mu_m, lv_m, mu_j, lv_j, es, dz, enc_act, dec_act, total;
+  int Zs;
+};
+__host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
+  WsLayout w;
+  w.Zs = rup(Z, 16);
+  int64_t o = 0;
+  int64_t lat = (int64_t)ROWS * w.Zs * 4;
+  w.mu_m = o; o += lat * M;
+  w.lv_m = o; o += lat * M;
+  w.mu_j = o; o += lat;
+  w.lv_j = o; o += lat;
+  w.es = o; o += lat;
+  w.dz = o; o += lat;
+  int64_t act = (int64_t)ROWS * PW * 2;
+  w.enc_act = o; o += act * M * L;
+  w.dec_act = o; o += act * L;
+  w.total = (o + 255) / 256 * 256;
+  return w;
+}
+
+// ---- small helpers ---------------------------------------------------------------------------
+__device__ inline float lrelu(float v, bool nl) { return (nl && v < 0.f) ? v * SLOPE : v; }
+
+__device__ inline unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+__device__ inline f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// A-operand fragment of a row-major bf16 LDS tile: lane holds buf[row][k .. k+7]
+__device__ inline bf16x8 lds_frag(const __bf16* buf, int ld, int row, int k) {
+  return *reinterpret_cast<const bf16x8*>(buf + row * ld + k);
+}
+
+// Transposed fragment: lane (c16, g) receives buf[r0 + 8g + j][c0 + c16], j = 0..7, i.e. the
+// operand of a contraction over the ROW index of a row-major tile.  Two ds_read_b64_tr_b16:
+// within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane
+// i receives column i of the four rows (cdna_hip_programming.md T10).  EXEC is all ones here.
+struct TrAddr { unsigned a; };
+__device__ inline unsigned tr_addr(const __bf16* buf, int ld, int r0, int c0, int lane) {
+  int i = lane & 15, g = lane >> 4;
+  int q = i >> 2, p = i & 3;
+  return lds_addr(buf + (r0 + 8 * g + q) * ld + c0 + 4 * p);
+}
+#define NM_TR_READ(dst, addr, OFF) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+
+__device__ inline bf16x8 join4(bf16x4 lo, bf16x4 hi) {
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// Scalar reference form of the transposed fragment (unit tests compare the two).
+__device__ inline bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, int r0, int c0, int lane) {
+  int c = c0 + (lane & 15), g = lane >> 4;
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = buf[(r0 + 8 * g + j) * ld + c];
+  return r;
+}
+
+// Forward weight fragment: W[n][k0 .. k0+7] (fp32, row-major [N][K]) -> bf16x8, zero outside.
+__device__ inline bf16x8 w_frag(const float* __restrict__ W, int N, int K, int n, int k0) {
+  bf16x8 r;
+  const float* src = W + (int64_t)n * K + k0;
+  if (n < N && k0 + 8 <= K && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    const float4* p = reinterpret_cast<const float4*>(src);
+    float4 a = p[0], b = p[1];
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int k = k0 + j;
+      float v = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
+      r[j] = (__bf16)v;
+    }
+  }
+  return r;
+}
+
+// Dgrad weight fragment: W[n0 + j][k] for j = 0..7 (contraction over the OUTPUT index n).
+__device__ inline bf16x8 w_frag_t(const float* __restrict__ W, int N, int K, int n0, int k) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int n = n0 + j;
+    float v = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
+    r[j] = (__bf16)v;
+  }
+  return r;
+}
+
+// Block-wide sum; every thread gets the result.  Fixed summation order (bitwise reproducible).
+__device__ inline float block_sum(const Ctx& c, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (c.lane == 0) c.red[c.wave] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) s += c.red[w];
+  return s;
+}
+
+// Counter-based standard normal for the in-kernel draw (eps == NULL): splitmix64 + Box-Muller.
+__device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ inline float randn_ctr(uint64_t seed, uint32_t step, uint32_t row, uint32_t z) {
+  uint64_t h = splitmix64(seed ^ ((uint64_t)step << 32) ^ ((uint64_t)row << 8) ^ z);
+  uint64_t h2 = splitmix64(h);
+  float u1 = ((uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1]
+  float u2 = (uint32_t)(h2 >> 40) * (1.0f / 16777216.0f);           // [0, 1)
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// Gradient sink: optional store + Adam (torch.optim.Adam, cVAE.py:1111-1116).
+__device__ inline void apply_grad(const Ctx& c, int64_t idx, float g) {
+  const nm_job_t* J = c.job;
+  if (c.flags & NM_F_GRADS) J->grads[idx] = g;
+  if (c.flags & NM_F_ADAM) {
+    float p = J->params[idx], m = J->adam_m[idx], v = J->adam_v[idx];
+    m = m + (g - m) * (1.0f - J->beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * J->beta2 + (1.0f - J->beta2) * g * g;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    float denom = sqrtf(v) * c.inv_bc2_sqrt + J->adam_eps;
+    p = p - c.step_size * (m / denom);
+    J->params[idx] = p; J->adam_m[idx] = m; J->adam_v[idx] = v;
+  }
+}
+
+// ---- cooperative copies ----------------------------------------------------------------------
+// global bf16 [256][PW] (saved activation) -> LDS [256][LDP]
+__device__ inline void load_act(const Ctx& c, __bf16* dst, const __bf16* src) {
+  // 256 rows x 16 pieces of 16 B
+  for (int p = c.tid; p < ROWS * (PW / 8); p += WG) {
+    int row = p >> 4, seg = p & 15;
+    uint4 v = *reinterpret_cast<const uint4*>(src + row * PW + seg * 8);
+    *reinterpret_cast<uint4*>(dst + row * LDP + seg * 8) = v;
+  }
+}
+
+// one 64-column chunk of the packed table xb into registers / into Q (pitch LDX)
+struct XStage { uint4 v[4]; };
+__device__ inline void xchunk_load(const Ctx& c, XStage& s, const uint16_t* xb, int Kx, int kc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int p = c.tid + i * WG;            // 2048 pieces of 16 B
+    int row = p >> 3, seg = p & 7;
+    int col = kc * XCH + seg * 8;
+    uint4 z = {0u, 0u, 0u, 0u};
+    s.v[i] = (col < Kx) ? *reinterpret_cast<const uint4*>(xb + (int64_t)(c.row0 + row) * Kx + col) : z;
+  }
+}
+__device__ inline void xchunk_store(const Ctx& c, const XStage& s, __bf16* Q) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int p = c.tid + i * WG;
+    int row = p >> 3, seg = p & 7;
+    *reinterpret_cast<uint4*>(Q + row * LDX + seg * 8) = s.v[i];
+  }
+}
+
+// ---- GEMM phase: forward layer, P -> P in place ---------------------------------------------
+// out[r][n] = act(sum_k P[r][k] W[n][k] + b[n]), n < N; column N := 1 (ones column feeding the
+// next layer's bias gradient), columns (N, wpad(N)) := 0.  Optionally saved to `save` (bf16
+// [256][PW]) for the backward pass.
+__device__ void fwd_layer_inplace(const Ctx& c, const float* W, const float* b, int N, int K, bool act,
+                                  __bf16* save) {
+  const int ksteps = wpad(K) / 32;
+  const int ntn = wpad(N) / 16;
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int n = (c.wn + 4 * t) * 16 + c.c16;
+    float bv = (n < N) ? b[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
+  }
+  bf16x8 bcur[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bcur[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, 8 * c.g);
+  for (int ks = 0; ks < ksteps; ++ks) {
+    bf16x8 bnext[2];
+    if (ks + 1 < ksteps) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bnext[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (ks + 1) * 32 + 8 * c.g);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if ((c.wn + 4 * t) < ntn) acc[mt][t] = mfma(a, bcur[t], acc[mt][t]);
+    }
+    if (ks + 1 < ksteps) { bcur[0] = bnext[0]; bcur[1] = bnext[1]; }
+  }
+  __syncthreads();                       // every wave has finished reading P
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int nt = c.wn + 4 * t;
+    if (nt >= ntn) continue;
+    int n = nt * 16 + c.c16;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+        float v = acc[mt][t][i];
+        v = (n < N) ? lrelu(v, act) : (n == N ? 1.0f : 0.0f);
+        __bf16 hv = (__bf16)v;
+        c.P[r * LDP + n] = hv;
+        if (save) save[r * PW + n] = hv;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- GEMM phase: first encoder layer, x streamed through Q in 64-column chunks ----------------
+__device__ void fwd_first_layer(const Ctx& c, const nm_modality_t& md, const float* W, const float* b, int N, int K,
+                                bool act, __bf16* save) {
+  const int Kx = md.Kx;
+  const int nch = (Kx + XCH - 1) / XCH;
+  const int ntn = wpad(N) / 16;
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int n = (c.wn + 4 * t) * 16 + c.c16;
+    float bv = (n < N) ? b[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
+  }
+  XStage st;
+  xchunk_load(c, st, md.xb, Kx, 0);
+  for (int kc = 0; kc < nch; ++kc) {
+    xchunk_store(c, st, c.Q);
+    __syncthreads();
+    if (kc + 1 < nch) xchunk_load(c, st, md.xb, Kx, kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      int kg = kc * XCH + ks * 32;
+      if (kg < Kx) {
+        bf16x8 bf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, kg + 8 * c.g);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          bf16x8 a = lds_frag(c.Q, LDX, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            if ((c.wn + 4 * t) < ntn) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int nt = c.wn + 4 * t;
+    if (nt >= ntn) continue;
+    int n = nt * 16 + c.c16;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+        float v = acc[mt][t][i];
+        v = (n < N) ? lrelu(v, act) : (n == N ? 1.0f : 0.0f);
+        __bf16 hv = (__bf16)v;
+        c.P[r * LDP + n] = hv;
+        if (save) save[r * PW + n] = hv;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
+__device__ void fwd_heads(const Ctx& c, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                          int Z, int K, float* mu_out, float* lv_out, int Zs) {
+  const int ksteps = wpad(K) / 32;
+  const int nzt = Zs / 16;
+  for (int nt = c.wn; nt < nzt; nt += 4) {
+    int n = nt * 16 + c.c16;
+    f32x4 am[8], al[8];
+    float b0 = (n < Z) ? bmu[n] : 0.f, b1 = (n < Z) ? blv[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) { am[mt] = f32x4{b0, b0, b0, b0}; al[mt] = f32x4{b1, b1, b1, b1}; }
+    for (int ks = 0; ks < ksteps; ++ks) {
+      bf16x8 fm = w_frag(Wmu, Z, K, n, ks * 32 + 8 * c.g);
+      bf16x8 fl = w_frag(Wlv, Z, K, n, ks * 32 + 8 * c.g);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+        am[mt] = mfma(a, fm, am[mt]);
+        al[mt] = mfma(a, fl, al[mt]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+        mu_out[r * Zs + n] = (n < Z) ? am[mt][i] : 0.f;
+        lv_out[r * Zs + n] = (n < Z) ? al[mt][i] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- dgrad: acc[r][k] += sum_n P[r][n] W[n][k]  (contraction over P's columns) -----------------
+// k tiles {wn, wn+4} of wpad(K); nsteps = 32-wide steps over P's columns; n_base = index of P's
+// column 0 in W's row space.
+__device__ inline void dgrad_acc(const Ctx& c, f32x4 (&acc)[8][2], const __bf16* A, const float* W, int N, int K,
+                                 int nsteps, int n_base) {
+  const int ntk = wpad(K) / 16;
+  for (int s = 0; s < nsteps; ++s) {
+    bf16x8 bf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      bf[t] = w_frag_t(W, N, K, n_base + s * 32 + 8 * c.g, (c.wn + 4 * t) * 16 + c.c16);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      bf16x8 a = lds_frag(A, LDP, c.wm * 128 + mt * 16 + c.c16, s * 32 + 8 * c.g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if ((c.wn + 4 * t) < ntk) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+    }
+  }
+}
+
+// dgrad through the two encoder heads: P columns [0,Zs) = d mu, [Zs,2Zs) = d logvar
+__device__ inline void dgrad_heads(const Ctx& c, f32x4 (&acc)[8][2], const float* Wmu, const float* Wlv, int Z, int K,
+                                   int Zs) {
+  const int ntk = wpad(K) / 16;
+  const int nsteps = rup(2 * Zs, 32) / 32;
+  for (int s = 0; s < nsteps; ++s) {
+    bf16x8 bf[2];
+    int nn0 = s * 32 + 8 * c.g;              // 8-aligned, Zs is a multiple of 16: never straddles
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int k = (c.wn + 4 * t) * 16 + c.c16;
+      bf[t] = (nn0 < Zs) ? w_frag_t(Wmu, Z, K, nn0, k) : w_frag_t(Wlv, Z, K, nn0 - Zs, k);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, s * 32 + 8 * c.g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if ((c.wn + 4 * t) < ntk) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+    }
+  }
+}
+
+// ---- wgrad + Adam: dW[n][k] = sum_r A[r][a_col0 + n] * B[r][k] -------------------------------
+// n in [0,N) (ntn tiles), B columns kk in [0, nkt*16) map to global k = k_base + kk; k < K is a
+// weight W[n][k], k == K the bias b[n] (ones column), beyond: nothing.  Work unit = one n-tile x
+// up to four k-tiles, dealt round-robin to the 8 waves.
+template <bool SCALAR_TR>
+__device__ void wgrad_adam(const Ctx& c, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb, int N, int K,
+                           int k_base, int nkt, int64_t w_off, int64_t b_off) {
+  const int ntn = (N + 15) / 16;
+  const int kgroups = (nkt + 3) / 4;
+  const int units = ntn * kgroups;
+  for (int u = c.wave; u < units; u += NWAVES) {
+    int nt = u / kgroups, kg = u % kgroups;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (SCALAR_TR) {
+      for (int rs = 0; rs < ROWS / 32; ++rs) {
+        bf16x8 a = lds_frag_tr_scalar(A, lda, rs * 32, a_col0 + nt * 16, c.lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          int kt = kg * 4 + t;
+          if (kt < nkt) {
+            bf16x8 b = lds_frag_tr_scalar(B, ldb, rs * 32, kt * 16, c.lane);
+            acc[t] = mfma(a, b, acc[t]);
+          }
+        }
+      }
+    } else {
+      unsigned aa = tr_addr(A, lda, 0, a_col0 + nt * 16, c.lane);
+      unsigned ba = tr_addr(B, ldb, 0, kg * 64, c.lane);
+      const unsigned a_step = 32u * lda * 2u, b_step = 32u * ldb * 2u;
+      const unsigned a4 = 4u * lda * 2u, b4 = 4u * ldb * 2u;
+      for (int rs = 0; rs < ROWS / 32; ++rs) {
+        bf16x4 a0, a1, b0[4], b1[4];
+        unsigned aa1 = aa + a4, ba1 = ba + b4;
+        NM_TR_READ(a0, aa, 0);
+        NM_TR_READ(a1, aa1, 0);
+        NM_TR_READ(b0[0], ba, 0);  NM_TR_READ(b1[0], ba1, 0);
+        NM_TR_READ(b0[1], ba, 32); NM_TR_READ(b1[1], ba1, 32);
+        NM_TR_READ(b0[2], ba, 64); NM_TR_READ(b1[2], ba1, 64);
+        NM_TR_READ(b0[3], ba, 96); NM_TR_READ(b1[3], ba1, 96);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]),
+                       "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
+        bf16x8 a = join4(a0, a1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (kg * 4 + t < nkt) acc[t] = mfma(a, join4(b0[t], b1[t]), acc[t]);
+        aa += a_step; ba += b_step;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int kt = kg * 4 + t;
+      if (kt >= nkt) continue;
+      int k = k_base + kt * 16 + c.c16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int n = nt * 16 + 4 * c.g + i;
+        if (n < N) {
+          if (k < K) apply_grad(c, w_off + (int64_t)n * K + k, acc[t][i]);
+          else if (k == K) apply_grad(c, b_off + n, acc[t][i]);
+        }
+      }
+    }
+  }
+}
+
+// P[r][k] = acc[r][k] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
+__device__ inline void finish_delta(const Ctx& c, const f32x4 (&acc)[8][2], const __bf16* src, int K, bool act) {
+  const int ntk = wpad(K) / 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int kt = c.wn + 4 * t;
+    if (kt >= ntk) continue;
+    int k = kt * 16 + c.c16;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+        float a = (float)src[r * LDP + k];
+        float d = acc[mt][t][i];
+        if (act && !(a > 0.f)) d *= SLOPE;
+        if (k >= K) d = 0.f;
+        c.P[r * LDP + k] = (__bf16)d;
+      }
+    }
+  }
+}
+
+__device__ inline void zero_acc(f32x4 (&acc)[8][2]) {
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+}
+
+// ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
+struct Fuse { float mu, lv, var; };
+__device__ inline void softmax_alpha(const nm_job_t* J, float* al) {
+  float mx = -INFINITY;
+  for (int m = 0; m < J->M; ++m) mx = fmaxf(mx, J->params[J->mod[m].alpha]);
+  float s = 0.f;
+  for (int m = 0; m < J->M; ++m) { al[m] = expf(J->params[J->mod[m].alpha] - mx); s += al[m]; }
+  for (int m = 0; m < J->M; ++m) al[m] /= s;
+}
+__device__ inline Fuse fuse_fwd(const nm_job_t* J, const float* mu, const float* lv, const float* al) {
+  const int M = J->M;
+  Fuse f;
+  if (M == 1 && J->single_bypass) { f.mu = mu[0]; f.var = expf(lv[0]); f.lv = logf(f.var); return f; }
+  int cb = J->combine;
+  if (cb == NM_COMBINE_POE || cb == NM_COMBINE_GPOE || cb == NM_COMBINE_MOPOE) {
+    float S = 0.f, Smu = 0.f;
+    for (int m = 0; m < M; ++m) {
+      float var = expf(lv[m]);
+      float w = (cb == NM_COMBINE_GPOE) ? al[m] / var : 1.0f / var;
+      S += w; Smu += mu[m] * w;
+    }
+    f.mu = Smu / S; f.var = 1.0f / S;
+    if (cb == NM_COMBINE_MOPOE) {
+      float sm = f.mu, sv = f.var;
+      for (int m = 0; m < M; ++m) { sm += mu[m]; sv += expf(lv[m]); }
+      f.mu = sm / (M + 1); f.var = sv / (M + 1);
+    }
+  } else {   // MoE: uniform weights
+    float sm = 0.f, sv = 0.f;
+    for (int m = 0; m < M; ++m) { sm += mu[m]; sv += expf(lv[m]); }
+    f.mu = sm / M; f.var = sv / M;
+  }
+  f.lv = logf(f.var);
+  return f;
+}
+// backward of the fusion for expert m: (d mu_j, d lv_j) -> (d mu_m, d lv_m), and d alpha_m (gPoE)
+__device__ inline void fuse_bwd(const nm_job_t* J, const float* mu, const float* lv, const float* al, int m,
+                                float dmu_j, float dlv_j, float& dmu_m, float& dlv_m, float& dalpha_m) {
+  const int M = J->M;
+  dalpha_m = 0.f;
+  if (M == 1 && J->single_bypass) { dmu_m = dmu_j; dlv_m = dlv_j; return; }
+  int cb = J->combine;
+  if (cb == NM_COMBINE_MOE) {
+    float sv = 0.f;
+    for (int q = 0; q < M; ++q) sv += expf(lv[q]);
+    dmu_m = dmu_j / M;
+    dlv_m = dlv_j * expf(lv[m]) / sv;                 // d log(mean var) / d lv_m
+    return;
+  }
+  // PoE family: precisions p_q (times alpha_q for gPoE)
+  float S = 0.f, Smu = 0.f;
+  for (int q = 0; q < M; ++q) {
+    float w = expf(-lv[q]) * ((cb == NM_COMBINE_GPOE) ? al[q] : 1.0f);
+    S += w; Smu += mu[q] * w;
+  }
+  float var_p = 1.0f / S, mu_p = Smu * var_p;
+  float pm = expf(-lv[m]);
+  float wm = pm * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);
+  float dmu_p = dmu_j, dlv_p = dlv_j;                 // gradients w.r.t. the PoE expert (mu_p, log var_p)
+  float extra_mu = 0.f, extra_lv = 0.f;
+  if (cb == NM_COMBINE_MOPOE) {
+    float sv = var_p;
+    for (int q = 0; q < M; ++q) sv += expf(lv[q]);
+    float var_j = sv / (M + 1);
+    dmu_p = dmu_j / (M + 1);
+    dlv_p = dlv_j * var_p / ((M + 1) * var_j);        // through var_p = exp(log var_p)
+    extra_mu = dmu_j / (M + 1);
+    extra_lv = dlv_j * expf(lv[m]) / ((M + 1) * var_j);
+  }
+  float r = var_p * wm;                               // sigma^2 * p_m
+  dmu_m = dmu_p * r + extra_mu;
+  dlv_m = -dmu_p * r * (mu[m] - mu_p) + dlv_p * r + extra_lv;
+  if (cb == NM_COMBINE_GPOE) dalpha_m = dmu_p * var_p * pm * (mu[m] - mu_p) - dlv_p * var_p * pm;
+}
+
+// ----------------------------------------------------------------------------------------------
+// The step: all phases for one tile of 256 rows.
+// ----------------------------------------------------------------------------------------------
+template <bool SCALAR_TR>
+__device__ void run_step(Ctx& c, int step) {
+  const nm_job_t* J = c.job;
+  const int M = J->M, L = J->L, Z = J->Z, C = J->C;
+  const bool nl = J->non_linear != 0;
+  const bool bwd = (c.flags & NM_F_BACKWARD) != 0;
+  const bool exportf = (c.flags & NM_F_EXPORT) != 0;
+  const WsLayout wl = ws_layout(M, L, Z);
+  const int Zs = wl.Zs;
+  float* ws_mu_m = reinterpret_cast<float*>(c.ws + wl.mu_m);
+  float* ws_lv_m = reinterpret_cast<float*>(c.ws + wl.lv_m);
+  float* ws_mu_j = reinterpret_cast<float*>(c.ws + wl.mu_j);
+  float* ws_lv_j = reinterpret_cast<float*>(c.ws + wl.lv_j);
+  float* ws_es = reinterpret_cast<float*>(c.ws + wl.es);
+  float* ws_dz = reinterpret_cast<float*>(c.ws + wl.dz);
+  __bf16* ws_enc = reinterpret_cast<__bf16*>(c.ws + wl.enc_act);
+  __bf16* ws_dec = reinterpret_cast<__bf16*>(c.ws + wl.dec_act);
+  const float* prm = J->params;
+
+  // ================= encoders =================
+  for (int m = 0; m < M; ++m) {
+    const nm_modality_t& md = J->mod[m];
+    __bf16* save0 = bwd ? ws_enc + (int64_t)(m * L + 0) * ROWS * PW : nullptr;
+    fwd_first_layer(c, md, prm + md.enc_w[0], prm + md.enc_b[0], J->H[0], md.D + C, nl, save0);
+    for (int e = 1; e < L; ++e) {
+      __bf16* sv = bwd ? ws_enc + (int64_t)(m * L + e) * ROWS * PW : nullptr;
+      fwd_layer_inplace(c, prm + md.enc_w[e], prm + md.enc_b[e], J->H[e], J->H[e - 1], nl, sv);
+    }
+    fwd_heads(c, prm + md.mu_w, prm + md.mu_b, prm + md.lv_w, prm + md.lv_b, Z, J->H[L - 1],
+              ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs);
+  }
+
+  // ================= fusion + reparameterisation + KL =================
+  float al[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
+  if (J->combine == NM_COMBINE_GPOE && !(M == 1 && J->single_bypass)) softmax_alpha(J, al);
+  float kl_part = 0.f;
+  for (int e = c.tid; e < ROWS * Z; e += WG) {
+    int r = e / Z, z = e - r * Z;
+    float mu[NM_MAX_MOD], lv[NM_MAX_MOD];
+    for (int m = 0; m < M; ++m) {
+      mu[m] = ws_mu_m[((int64_t)m * ROWS + r) * Zs + z];
+      lv[m] = ws_lv_m[((int64_t)m * ROWS + r) * Zs + z];
+    }
+    Fuse f = fuse_fwd(J, mu, lv, al);
+    float ep = J->eps ? J->eps[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + z]
+                      : randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)z);
+    float es = ep * expf(0.5f * f.lv);
+    float zz = f.mu + es;
+    ws_mu_j[r * Zs + z] = f.mu;
+    ws_lv_j[r * Zs + z] = f.lv;
+    ws_es[r * Zs + z] = es;
+    ws_dz[r * Zs + z] = 0.f;
+    if (r < c.nrows) {
+      kl_part += -0.5f * (1.0f + f.lv - f.mu * f.mu - expf(f.lv));
+      if (exportf) {
+        int64_t gr = (int64_t)(c.row0 + r) * Z + z;
+        if (J->out_mu) J->out_mu[gr] = f.mu;
+        if (J->out_logvar) J->out_logvar[gr] = f.lv;
+        if (J->out_z) J->out_z[gr] = zz;
+      }
+    }
+  }
+  float kl = block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
+
+  // ================= decoders (forward, NLL, and the whole decoder backward) =================
+  float ll_m[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < M; ++m) {
+    const nm_modality_t& md = J->mod[m];
+    const int D = md.D;
+    // --- build zc = [z | c | 1 | 0] in P ---
+    const int Kd0 = Z + C;
+    for (int e = c.tid; e < ROWS * wpad(Kd0); e += WG) {
+      int wz = wpad(Kd0);
+      int r = e / wz, k = e - r * wz;
+      float v;
+      if (k < Z) v = ws_mu_j[r * Zs + k] + ws_es[r * Zs + k];
+      else if (k < Kd0) v = (float)reinterpret_cast<const __bf16*>(md.xb)[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
+      else v = (k == Kd0) ? 1.0f : 0.0f;
+      c.P[r * LDP + k] = (__bf16)v;
+    }
+    __syncthreads();
+    // --- hidden decoder layers ---
+    for (int d = 0; d < L; ++d) {
+      int Kin = (d == 0) ? Kd0 : J->H[L - d];
+      int Nout = J->H[L - 1 - d];
+      __bf16* sv = (bwd && d < L - 1) ? ws_dec + (int64_t)d * ROWS * PW : nullptr;
+      fwd_layer_inplace(c, prm + md.dec_w[d], prm + md.dec_b[d], Nout, Kin, nl, sv);
+    }
+    // --- output layer in chunks of 128 ROI columns, fused with NLL, its backward and Adam ---
+    const int Hl = J->H[0];                       // width feeding the output layer
+    const float* Wo = prm + md.out_w;
+    const float* bo = prm + md.out_b;
+    const float* lvo = prm + md.logvar_out;
+    f32x4 accg[8][2];
+    zero_acc(accg);
+    float nll_part = 0.f;
+    if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
+    const int nchunks = (D + PW - 1) / PW;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int d0 = ch * PW;
+      const int valid = min(PW, D - d0);
+      if (c.tid < PW) c.colacc[c.tid] = 0.f;
+      __syncthreads();
+      // x_hat chunk
+      {
+        f32x4 acc[8][2];
+        const int ksteps = wpad(Hl) / 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          int d = d0 + (c.wn + 4 * t) * 16 + c.c16;
+          float bv = (d < D) ? bo[d] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
+        }
+        for (int ks = 0; ks < ksteps; ++ks) {
+          bf16x8 bf[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bf[t] = w_frag(Wo, D, Hl, d0 + (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+            bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+          }
+        }
+        // epilogue: residual, NLL, d logvar_out, delta chunk -> Q
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          int dl = (c.wn + 4 * t) * 16 + c.c16;     // column inside the chunk
+          int d = d0 + dl;
+          bool dv = d < D;
+          float s = dv ? lvo[d] : 0.f;
+          float inv = expf(-s);
+          float colsum = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+              bool ok = dv && r < c.nrows;
+              float delta = 0.f;
+              if (ok) {
+                int64_t gi = (int64_t)(c.row0 + r) * D + d;
+                float x = md.x_f32[gi];
+                float xh = acc[mt][t][i];
+                float diff = xh - x;
+                float q = diff * diff * inv;
+                nll_part += 0.5f * q + 0.5f * s + LOG_SQRT_2PI;
+                colsum += 0.5f - 0.5f * q;
+                delta = J->ll_weight * diff * inv * c.inv_b;
+                if (exportf) {
+                  if (md.out_loc) md.out_loc[gi] = xh;
+                  if (md.out_sqerr) md.out_sqerr[gi] = diff * diff;
+                  if (md.out_rowdev) atomicAdd(&c.rowacc[r], diff * diff);
+                }
+              }
+              if (bwd) c.Q[r * LDP + dl] = (__bf16)delta;
+            }
+          }
+          if (bwd) {
+            colsum += __shfl_xor(colsum, 16, 64);
+            colsum += __shfl_xor(colsum, 32, 64);
+            if (c.g == 0 && dv) atomicAdd(&c.colacc[dl], colsum);
+          }
+        }
+      }
+      if (!bwd) continue;
+      __syncthreads();
+      // d logvar_out for this chunk
+      if (c.tid < valid) apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b);
+      // dgrad into the last hidden activation: accg[r][k] += sum_d Q[r][d] Wo[d0 + d][k]
+      dgrad_acc(c, accg, c.Q, Wo, D, Hl, rup(valid, 32) / 32, d0);
+      __syncthreads();                              // all reads of the old Wo are done
+      // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
+      wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, (Hl + 1 + 15) / 16,
+                            md.out_w + (int64_t)d0 * Hl, md.out_b + d0);
+      __syncthreads();
+    }
+    float nll = block_sum(c, nll_part);
+    ll_m[m] = -nll * c.inv_b;                       // compute_ll: sum over ROI, mean over rows
+    if (exportf && md.out_rowdev) {
+      __syncthreads();
+      for (int r = c.tid; r < c.nrows; r += WG) md.out_rowdev[c.row0 + r] = c.rowacc[r] / (float)D;
+    }
+    if (!bwd) { __syncthreads(); continue; }
+
+    // --- decoder hidden layers, backward ---
+    // state: P = activation g_{L-1}, accg = pre-mask delta of g_{L-1}
+    finish_delta(c, accg, c.P, Hl, nl);             // mask source is P itself (same element)
+    __syncthreads();
+    for (int d = L - 1; d >= 0; --d) {
+      int Kin = (d == 0) ? Kd0 : J->H[L - d];
+      int Nout = J->H[L - 1 - d];
+      // Q <- input activation of decoder layer d
+      if (d == 0) {
+        for (int e = c.tid; e < ROWS * wpad(Kd0); e += WG) {
+          int wz = wpad(Kd0);
+          int r = e / wz, k = e - r * wz;
+          float v;
+          if (k < Z) v = ws_mu_j[r * Zs + k] + ws_es[r * Zs + k];
+          else if (k < Kd0) v = (float)reinterpret_cast<const __bf16*>(md.xb)[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
+          else v = (k == Kd0) ? 1.0f : 0.0f;
+          c.Q[r * LDP + k] = (__bf16)v;
+        }
+      } else {
+        load_act(c, c.Q, ws_dec + (int64_t)(d - 1) * ROWS * PW);
+      }
+      __syncthreads();
+      f32x4 acc[8][2];
+      zero_acc(acc);
+      dgrad_acc(c, acc, c.P, prm + md.dec_w[d], Nout, Kin, wpad(Nout) / 32, 0);
+      __syncthreads();                              // old weights fully read
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, (Kin + 1 + 15) / 16, md.dec_w[d], md.dec_b[d]);
+      __syncthreads();
+      if (d > 0) {
+        finish_delta(c, acc, c.Q, Kin, nl);
+      } else {
+        // d z: accumulate over decoders (fixed element -> thread ownership, no race)
+        const int ntk = wpad(Kin) / 16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          int kt = c.wn + 4 * t;
+          if (kt >= ntk) continue;
+          int k = kt * 16 + c.c16;
+          if (k < Z) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+                ws_dz[r * Zs + k] += acc[mt][t][i];
+              }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ================= loss log =================
+  {
+    float ll_sum = 0.f;
+    for (int m = 0; m < M; ++m) ll_sum += ll_m[m];
+    if (c.tid == 0 && J->loss_log) {
+      float* row = J->loss_log + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
+      row[NM_LOSS_KL] = J->kl_weight * kl;
+      row[NM_LOSS_LL] = ll_sum;
+      row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
+      for (int m = 0; m < M; ++m) row[NM_LOSS_LL_M + m] = ll_m[m];
+    }
+  }
+  if (!bwd) return;
+
+  // ================= fusion backward: alpha gradients (gPoE) =================
+  const bool fused = !(M == 1 && J->single_bypass);
+  const float klw = J->kl_weight * c.inv_b;
+  if (fused && J->combine == NM_COMBINE_GPOE) {
+    float dal[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = c.tid; e < c.nrows * Z; e += WG) {
+      int r = e / Z, z = e - r * Z;
+      float mu[NM_MAX_MOD], lv[NM_MAX_MOD];
+      for (int m = 0; m < M; ++m) {
+        mu[m] = ws_mu_m[((int64_t)m * ROWS + r) * Zs + z];
+        lv[m] = ws_lv_m[((int64_t)m * ROWS + r) * Zs + z];
+      }
+      float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
+      float dmu_j = dz + klw * mj;
+      float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
+      for (int m = 0; m < M; ++m) {
+        float a, b, da;
+        fuse_bwd(J, mu, lv, al, m, dmu_j, dlv_j, a, b, da);
+        dal[m] += da;
+      }
+    }
+    float tot[NM_MAX_MOD];
+    for (int m = 0; m < M; ++m) tot[m] = block_sum(c, dal[m]);
+    if (c.tid == 0) {
+      float dot = 0.f;
+      for (int m = 0; m < M; ++m) dot += al[m] * tot[m];
+      for (int m = 0; m < M; ++m) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
+    }
+    __syncthreads();
+  }
+
+  // ================= encoders, backward =================
+  for (int m = 0; m < M; ++m) {
+    const nm_modality_t& md = J->mod[m];
+    const int Hh = J->H[L - 1];
+    const int whp = rup(2 * Zs, 32);
+    // P <- [d mu_m | d logvar_m], Q <- last hidden activation
+    for (int e = c.tid; e < ROWS * whp; e += WG) {
+      int r = e / whp, k = e - r * whp;
+      int z = (k < Zs) ? k : k - Zs;
+      float v = 0.f;
+      if (z < Z && k < 2 * Zs && r < c.nrows) {
+        float mu[NM_MAX_MOD], lv[NM_MAX_MOD];
+        for (int q = 0; q < M; ++q) {
+          mu[q] = ws_mu_m[((int64_t)q * ROWS + r) * Zs + z];
+          lv[q] = ws_lv_m[((int64_t)q * ROWS + r) * Zs + z];
+        }
+        float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
+        float dmu_j = dz + klw * mj;
+        float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
+        float a, b, da;
+        fuse_bwd(J, mu, lv, al, m, dmu_j, dlv_j, a, b, da);
+        v = (k < Zs) ? a : b;
+      }
+      c.P[r * LDP + k] = (__bf16)v;
+    }
+    load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW);
+    __syncthreads();
+    f32x4 acc[8][2];
+    zero_acc(acc);
+    dgrad_heads(c, acc, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
+    __syncthreads();
+    wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, (Hh + 1 + 15) / 16, md.mu_w, md.mu_b);
+    wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, (Hh + 1 + 15) / 16, md.lv_w, md.lv_b);
+    __syncthreads();
+    finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
+    __syncthreads();
+    for (int e = L - 1; e >= 1; --e) {
+      int Kin = J->H[e - 1], Nout = J->H[e];
+      load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW);
+      __syncthreads();
+      zero_acc(acc);
+      dgrad_acc(c, acc, c.P, prm + md.enc_w[e], Nout, Kin, wpad(Nout) / 32, 0);
+      __syncthreads();
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, (Kin + 1 + 15) / 16, md.enc_w[e], md.enc_b[e]);
+      __syncthreads();
+      finish_delta(c, acc, c.Q, Kin, nl);
+      __syncthreads();
+    }
+    // first encoder layer: dW[n][k] = sum_r P[r][n] xc[r][k], x streamed through Q
+    {
+      const int Kx = md.Kx, K0 = md.D + C, N0 = J->H[0];
+      const int nch = (Kx + XCH - 1) / XCH;
+      XStage st;
+      xchunk_load(c, st, md.xb, Kx, 0);
+      for (int kc = 0; kc < nch; ++kc) {
+        xchunk_store(c, st, c.Q);
+        __syncthreads();
+        if (kc + 1 < nch) xchunk_load(c, st, md.xb, Kx, kc + 1);
+        int cols = min(XCH, Kx - kc * XCH);
+        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDX, N0, K0, kc * XCH, cols / 16, md.enc_w[0], md.enc_b[0]);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+template <bool SCALAR_TR>
+__global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict__ jobs, int step0, int steps_per_tile,
+                                                     int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const nm_job_t* J = jobs + blockIdx.x;
+  Ctx c;
+  c.job = J;
+  c.P = reinterpret_cast<__bf16*>(smem);
+  c.Q = c.P + ROWS * LDP;
+  c.red = reinterpret_cast<float*>(c.Q + ROWS * LDP);
+  c.colacc = c.red + 64;
+  c.rowacc = c.colacc + 128;
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave = c.tid >> 6;
+  c.wm = c.wave >> 2;
+  c.wn = c.wave & 3;
+  c.g = c.lane >> 4;
+  c.c16 = c.lane & 15;
+  c.flags = flags;
+  c.ws = reinterpret_cast<char*>(J->workspace) + (int64_t)blockIdx.y * J->workspace_stride;
+  // zero LDS once: padded columns are multiplied by zero weights and must stay finite
+  for (int i = c.tid; i < 2 * ROWS * LDP / 2; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  __syncthreads();
+  const int nb = (J->n_rows + ROWS - 1) / ROWS;
+  double b1p = J->beta1_pow, b2p = J->beta2_pow;
+  const int s_begin = step0 + blockIdx.y * steps_per_tile;
+  for (int s = s_begin; s < s_begin + steps_per_tile; ++s) {
+    int b = s % nb;
+    c.row0 = b * ROWS;
+    c.nrows = min(ROWS, J->n_rows - c.row0);
+    c.inv_b = 1.0f / (float)c.nrows;
+    b1p *= (double)J->beta1;
+    b2p *= (double)J->beta2;
+    c.step_size = (float)((double)J->lr / (1.0 - b1p));
+    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2p));
+    run_step<SCALAR_TR>(c, s);
+    __syncthreads();
+  }
+}
+
+// ---- stand-alone kernels ----------------------------------------------------------------------
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
+                                 float inv_bc2_sqrt) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float gg = g[i], mm = m[i], vv = v[i];
+    mm = mm + (gg - mm) * (1.0f - b1);
+    vv = vv * b2 + (1.0f - b2) * gg * gg;
+    float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mm / denom);
+    m[i] = mm; v[i] = vv;
+  }
+}
+
+__global__ void pack_table_kernel(const float* __restrict__ x, const float* __restrict__ cc, int n_rows, int rows_alloc,
+                                  int D, int C, int Kx, uint16_t* __restrict__ xb, float* __restrict__ xf) {
+  int64_t total = (int64_t)rows_alloc * Kx;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / Kx), k = (int)(i - (int64_t)r * Kx);
+    float v = 0.f;
+    if (r < n_rows) {
+      if (k < D) v = x[(int64_t)r * D + k];
+      else if (k < D + C) v = cc[(int64_t)r * C + (k - D)];
+      else if (k == D + C) v = 1.0f;
+    }
+    __bf16 h = (__bf16)v;
+    xb[i] = __builtin_bit_cast(uint16_t, h);
+    if (xf && k < D) xf[(int64_t)r * D + k] = (r < n_rows) ? x[(int64_t)r * D + k] : 0.f;
+  }
+}
+
+// Unit-test kernel: one workgroup, C[M][N] = A[M][K] B[N][K]^T via the production fragment loaders.
+//   mode 0  forward form : A (M=256 rows, K<=128) staged row-major in P, B fp32 [N][K]
+//   mode 1  dgrad form   : C[r][k] = sum_n A[r][n] B[n][k]  (A [256][N'], B fp32 [N'][K'])
+//   mode 2/3 wgrad form  : C[n][k] = sum_r A[r][n] B[r][k]  (tr-read / scalar loaders)
+__global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A, const float* B, float* Cout, int M,
+                                                       int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Ctx c;
+  c.P = reinterpret_cast<__bf16*>(smem);
+  c.Q = c.P + ROWS * LDP;
+  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.wm = c.wave >> 2; c.wn = c.wave & 3;
+  c.g = c.lane >> 4; c.c16 = c.lane & 15;
+  for (int i = c.tid; i < 2 * ROWS * LDP / 2; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  __syncthreads();
+  if (mode == 0 || mode == 1) {
+    // A is [256][KA] with KA = (mode == 0 ? K : N)
+    int KA = (mode == 0) ? K : N;
+    for (int e = c.tid; e < ROWS * KA; e += WG) { int r = e / KA, k = e - r * KA; c.P[r * LDP + k] = (__bf16)A[e]; }
+    __syncthreads();
+    f32x4 acc[8][2];
+    zero_acc(acc);
+    int ncols = (mode == 0) ? N : K;
+    if (mode == 0) {
+      for (int ks = 0; ks < rup(K, 32) / 32; ++ks) {
+        bf16x8 bf[2];
+        for (int t = 0; t < 2; ++t) bf[t] = w_frag(B, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+        }
+      }
+    } else {
+      // emulate wpad semantics: dgrad_acc masks k tiles with wpad(K)
+      dgrad_acc(c, acc, c.P, B, N, K, rup(N, 32) / 32, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int n = (c.wn + 4 * t) * 16 + c.c16;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
+          if (n < ncols) Cout[(int64_t)r * ncols + n] = acc[mt][t][i];
+        }
+    }
+  } else {
+    // A [256][N], B [256][K]; output [N][K]
+    for (int e = c.tid; e < ROWS * N; e += WG) { int r = e / N, k = e - r * N; c.P[r * LDP + k] = (__bf16)A[e]; }
+    for (int e = c.tid; e < ROWS * K; e += WG) { int r = e / K, k = e - r * K; c.Q[r * LDP + k] = (__bf16)B[e]; }
+    __syncthreads();
+    const int ntn = (N + 15) / 16, nkt = (K + 15) / 16, kgroups = (nkt + 3) / 4;
+    for (int u = c.wave; u < ntn * kgroups; u += NWAVES) {
+      int nt = u / kgroups, kg = u % kgroups;
+      f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+      for (int rs = 0; rs < ROWS / 32; ++rs) {
+        bf16x8 a;
+        bf16x8 b[4];
+        if (mode == 3) {
+          a = lds_frag_tr_scalar(c.P, LDP, rs * 32, nt * 16, c.lane);
+          for (int t = 0; t < 4; ++t) b[t] = lds_frag_tr_scalar(c.Q, LDP, rs * 32, (kg * 4 + t) * 16, c.lane);
+        } else {
+          unsigned aa = tr_addr(c.P, LDP, rs * 32, nt * 16, c.lane);
+          unsigned ba = tr_addr(c.Q, LDP, rs * 32, kg * 64, c.lane);
+          unsigned aa1 = aa + 4u * LDP * 2u, ba1 = ba + 4u * LDP * 2u;
+          bf16x4 a0, a1, b0[4], b1[4];
+          NM_TR_READ(a0, aa, 0); NM_TR_READ(a1, aa1, 0);
+          NM_TR_READ(b0[0], ba, 0);  NM_TR_READ(b1[0], ba1, 0);
+          NM_TR_READ(b0[1], ba, 32); NM_TR_READ(b1[1], ba1, 32);
+          NM_TR_READ(b0[2], ba, 64); NM_TR_READ(b1[2], ba1, 64);
+          NM_TR_READ(b0[3], ba, 96); NM_TR_READ(b1[3], ba1, 96);
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]),
+                         "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
+          a = join4(a0, a1);
+          for (int t = 0; t < 4; ++t) b[t] = join4(b0[t], b1[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma(a, b[t], acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int k = (kg * 4 + t) * 16 + c.c16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int n = nt * 16 + 4 * c.g + i;
+          if (n < N && k < K) Cout[(int64_t)n * K + k] = acc[t][i];
+        }
+      }
+    }
+  }
+}
+
+constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (64 + 128 + 256) * 4;
+
+}  // namespace
+
+// ================================= C ABI ========================================================
+extern "C" {
+
+int nm_version(void) { return 1; }
+
+int nm_abi_sizes(int64_t* sizeof_job, int64_t* sizeof_modality) {
+  if (!sizeof_job || !sizeof_modality) return -1;
+  *sizeof_job = (int64_t)sizeof(nm_job_t);
+  *sizeof_modality = (int64_t)sizeof(nm_modality_t);
+  return 0;
+}
+
+const char* nm_status_string(int status) {
+  switch (status) {
+    case 0: return "ok";
+    case -1: return "null pointer";
+    case -2: return "modalities out of range (1..NM_MAX_MOD)";
+    case -3: return "hidden layers out of range (1..NM_MAX_HID)";
+    case -4: return "hidden width out of range (1..NM_MAX_WIDTH)";
+    case -5: return "latent out of range (1..NM_MAX_LATENT)";
+    case -6: return "latent + c_dim exceeds NM_MAX_WIDTH";
+    case -7: return "table pitch Kx must be a multiple of 32 and >= D + C + 1";
+    case -8: return "bad launch geometry";
+    case -9: return "unknown combine";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
+  }
+}
+
+int nm_validate_job(const nm_job_t* j) {
+  if (!j) return -1;
+  if (j->M < 1 || j->M > NM_MAX_MOD) return -2;
+  if (j->L < 1 || j->L > NM_MAX_HID) return -3;
+  for (int i = 0; i < j->L; ++i)
+    if (j->H[i] < 1 || j->H[i] > NM_MAX_WIDTH) return -4;
+  if (j->Z < 1 || j->Z > NM_MAX_LATENT) return -5;
+  if (j->Z + j->C > NM_MAX_WIDTH) return -6;
+  if (j->combine < 0 || j->combine > NM_COMBINE_MOPOE) return -9;
+  for (int m = 0; m < j->M; ++m) {
+    const nm_modality_t& md = j->mod[m];
+    if (md.Kx % 32 != 0 || md.Kx < md.D + j->C + 1) return -7;
+  }
+  return 0;
+}
+
+int64_t nm_workspace_bytes(const nm_job_t* j) {
+  if (!j) return -1;
+  return ws_layout(j->M, j->L, j->Z).total;
+}
+
+static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
+                       void* stream, bool scalar_tr) {
+  if (!jobs_dev) return -1;
+  if (n_jobs < 1 || steps_per_tile < 1 || n_tiles < 1 || step0 < 0) return -8;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(n_jobs, n_tiles), block(WG);
+  hipError_t e;
+  if (scalar_tr) {
+    e = hipFuncSetAttribute((const void*)nm_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(nm_step_kernel<true>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags);
+  } else {
+    e = hipFuncSetAttribute((const void*)nm_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(nm_step_kernel<false>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags);
+  }
+  return (int)hipGetLastError();
+}
+
+int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
+              void* stream) {
+  return launch_impl(jobs_dev, n_jobs, step0, steps_per_tile, n_tiles, flags, stream, false);
+}
+
+/* same as nm_launch but with the scalar transposing loader (validation of ds_read_b64_tr_b16) */
+int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
+                        void* stream) {
+  return launch_impl(jobs_dev, n_jobs, step0, steps_per_tile, n_tiles, flags, stream, true);
+}
+
+int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream) {
+  return nm_launch(jobs_dev, n_jobs, step0, n_steps, 1, NM_F_BACKWARD | NM_F_ADAM, stream);
+}
+
+int nm_grads(const nm_job_t* jobs_dev, int n_jobs, int step, void* stream) {
+  return nm_launch(jobs_dev, n_jobs, step, 1, 1, NM_F_BACKWARD | NM_F_GRADS | NM_F_EXPORT, stream);
+}
+
+int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream) {
+  return nm_launch(jobs_dev, n_jobs, tile0, 1, n_tiles, NM_F_EXPORT, stream);
+}
+
+int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int64_t t, void* stream) {
+  if (!params || !grads || !m || !v) return -1;
+  if (n <= 0 || t < 1) return -8;
+  double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  float step_size = (float)((double)lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, beta1,
+                     beta2, eps, step_size, inv_bc2_sqrt);
+  return (int)hipGetLastError();
+}
+
+int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx, uint16_t* xb,
+                  float* x_f32_out, void* stream) {
+  if (!x || !xb || (C > 0 && !c)) return -1;
+  if (Kx % 32 != 0 || Kx < D + C + 1 || rows_alloc < n_rows || rows_alloc % NM_BATCH != 0) return -7;
+  int64_t total = (int64_t)rows_alloc * Kx;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, c, n_rows, rows_alloc, D, C,
+                     Kx, xb, x_f32_out);
+  return (int)hipGetLastError();
+}
+
+int nm_test_gemm(int mode, const float* A, const float* B, float* Cout, int M, int N, int K, void* stream) {
+  if (!A || !B || !Cout) return -1;
+  if (M != ROWS || mode < 0 || mode > 3) return -8;
+  if (mode == 0 && (K > PW || N > PW)) return -8;
+  if (mode == 1 && (N > PW || K > 96)) return -8;
+  if (mode >= 2 && (N > PW || K > PW)) return -8;
+  hipError_t e = hipFuncSetAttribute((const void*)test_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(test_gemm_kernel, dim3(1), dim3(WG), SMEM_BYTES, (hipStream_t)stream, mode, A, B, Cout, M, N, K);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""Host side of the HIP path: ROI tables resident in HBM, job descriptors, launches.
+
+A *job* is one independent model of the sweep (a (fold, procedure) cell): its packed ROI
+tables, flat fp32 parameters, Adam moments and workspace.  A *JobSet* is the device array
+of descriptors one kernel launch runs -- one workgroup per job.
+PyTorch is used for device memory and streams only; all arithmetic is in libnmhip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .layout import ModelSpec, ParamLayout
+
+BATCH = _lib.NM_BATCH
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.NmError("no HIP device visible: the cVAE hot path runs on MI355X only (no CPU fallback)")
+    return torch.device(device if device is not None else "cuda:0")
+
+
+class Table:
+    """One modality's ROI table in HBM.
+
+    ``x`` [N, D] and covariates ``c`` [N, C] (any float/int dtype; the reference's
+    ``torch.cat((x, c))`` promotes to float32, cVAE.py:163) become
+      x_f32 [rows_alloc, D]  fp32, zero rows beyond N        (residual / NLL side)
+      xb    [rows_alloc, Kx] bf16  x | c | 1 | 0             (MFMA operand side)
+    with rows_alloc a multiple of 256 and Kx a multiple of 32.
+    """
+
+    def __init__(self, x, c, device=None):
+        dev = require_gpu(device)
+        lib = _lib.load()
+        x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+        c = torch.as_tensor(np.asarray(c) if not torch.is_tensor(c) else c)
+        if x.dim() != 2 or c.dim() != 2 or x.shape[0] != c.shape[0]:
+            raise ValueError(f"x must be [N, D] and c [N, C] with equal N, got {tuple(x.shape)} / {tuple(c.shape)}")
+        self.N, self.D = int(x.shape[0]), int(x.shape[1])
+        self.C = int(c.shape[1])
+        self.rows_alloc = max(1, math.ceil(self.N / BATCH)) * BATCH
+        self.Kx = (self.D + self.C + 1 + 31) // 32 * 32
+        xs = x.to(device=dev, dtype=torch.float32).contiguous()
+        cs = c.to(device=dev, dtype=torch.float32).contiguous()
+        self.x_f32 = torch.empty(self.rows_alloc, self.D, dtype=torch.float32, device=dev)
+        self.xb = torch.empty(self.rows_alloc, self.Kx, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.nm_pack_table(xs.data_ptr(), cs.data_ptr() if self.C > 0 else None, self.N, self.rows_alloc,
+                                     self.D, self.C, self.Kx, self.xb.data_ptr(), self.x_f32.data_ptr(),
+                                     _stream_ptr(dev)), "nm_pack_table")
+        self.device = dev
+
+    @property
+    def n_tiles(self) -> int:
+        return self.rows_alloc // BATCH
+
+
+class Job:
+    """Parameters + optimizer state + tables of one model."""
+
+    def __init__(self, spec: ModelSpec, tables: Sequence[Table], combine: str = "poe", state: Optional[Dict] = None,
+                 lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, kl_weight: Optional[float] = None,
+                 ll_weight: float = 1.0, seed: int = 0, loss_cap: int = 1024, single_bypass: bool = True,
+                 init_seed: int = 42, n_tiles_ws: int = 1):
+        self.layout = ParamLayout(spec)
+        self.spec = spec
+        if len(tables) != spec.M:
+            raise ValueError(f"need {spec.M} tables, got {len(tables)}")
+        for m, t in enumerate(tables):
+            if t.D != spec.input_dims[m] or t.C != spec.c_dim:
+                raise ValueError(f"table {m}: D={t.D}, C={t.C} do not match the model ({spec.input_dims[m]}, {spec.c_dim})")
+            if t.N != tables[0].N:
+                raise ValueError("all modalities must hold the same subjects (rows)")
+        combine_l = combine.lower()
+        if combine_l not in _lib.NM_COMBINE:
+            raise ValueError("No such combination method")            # cVAE.py:1163
+        self.combine = combine_l
+        self.tables = list(tables)
+        dev = tables[0].device
+        self.device = dev
+        if state is None:
+            state = self.layout.init_reference_rule(init_seed)
+        self.params = self.layout.flatten(state, device=dev)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.grads = torch.zeros_like(self.params)
+        self.lr, self.betas, self.adam_eps = float(lr), (float(betas[0]), float(betas[1])), float(adam_eps)
+        # cVAE_multimodal adds KL once per modality (cVAE.py:1189-1195); class cVAE once (cVAE.py:497-500)
+        self.kl_weight = float(spec.M if kl_weight is None else kl_weight)
+        self.ll_weight = float(ll_weight)
+        self.single_bypass = bool(single_bypass)
+        self.seed = int(seed)
+        self.t = 0                       # optimizer steps taken
+        self.step = 0                    # data steps taken (selects the batch)
+        self.loss_cap = int(loss_cap)
+        self.loss_log = torch.zeros(self.loss_cap, _lib.NM_LOSS_STRIDE, dtype=torch.float32, device=dev)
+        self.eps: Optional[torch.Tensor] = None
+        self.eps_cap = 1
+        self._ws = None
+        self._ws_tiles = 0
+        self._ensure_workspace(n_tiles_ws)
+        # optional exports
+        self.out_mu = self.out_logvar = self.out_z = None
+        self.out_loc: List[Optional[torch.Tensor]] = [None] * spec.M
+        self.out_sqerr: List[Optional[torch.Tensor]] = [None] * spec.M
+        self.out_rowdev: List[Optional[torch.Tensor]] = [None] * spec.M
+
+    # -- buffers -------------------------------------------------------------------------------
+    def _ensure_workspace(self, n_tiles: int):
+        if self._ws is not None and self._ws_tiles >= n_tiles:
+            return
+        lib = _lib.load()
+        probe = _lib.NmJob()
+        probe.M, probe.L, probe.Z = self.spec.M, len(self.spec.hidden), self.spec.latent
+        self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
+        self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
+        self._ws_tiles = n_tiles
+
+    def set_eps(self, eps: Optional[torch.Tensor]):
+        """Explicit reparameterisation draws [n_steps, 256, Z] (parity mode); None = in-kernel generator."""
+        if eps is None:
+            self.eps, self.eps_cap = None, 1
+            return
+        e = torch.as_tensor(eps, dtype=torch.float32)
+        if e.dim() == 2:
+            e = e.unsqueeze(0)
+        if e.shape[1] != BATCH or e.shape[2] != self.spec.latent:
+            pad = torch.zeros(e.shape[0], BATCH, self.spec.latent, dtype=torch.float32)
+            pad[:, :e.shape[1]] = e
+            e = pad
+        self.eps = e.to(self.device).contiguous()
+        self.eps_cap = int(self.eps.shape[0])
+
+    def enable_exports(self, loc=True, sqerr=True, rowdev=True, latent=True):
+        ra = self.tables[0].rows_alloc
+        Z = self.spec.latent
+        if latent:
+            self.out_mu = torch.zeros(ra, Z, device=self.device)
+            self.out_logvar = torch.zeros(ra, Z, device=self.device)
+            self.out_z = torch.zeros(ra, Z, device=self.device)
+        for m, t in enumerate(self.tables):
+            self.out_loc[m] = torch.zeros(ra, t.D, device=self.device) if loc else None
+            self.out_sqerr[m] = torch.zeros(ra, t.D, device=self.device) if sqerr else None
+            self.out_rowdev[m] = torch.zeros(ra, device=self.device) if rowdev else None
+
+    # -- descriptor ----------------------------------------------------------------------------
+    def struct(self) -> _lib.NmJob:
+        s, j = self.spec, _lib.NmJob()
+        j.M, j.C, j.L, j.Z = s.M, s.c_dim, len(s.hidden), s.latent
+        for i, h in enumerate(s.hidden):
+            j.H[i] = h
+        j.combine = _lib.NM_COMBINE[self.combine]
+        j.single_bypass = 1 if self.single_bypass else 0
+        j.n_rows = self.tables[0].N
+        j.non_linear = 1 if s.non_linear else 0
+        j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
+        j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
+        j.beta1_pow = self.betas[0] ** self.t
+        j.beta2_pow = self.betas[1] ** self.t
+        j.kl_weight, j.ll_weight = self.kl_weight, self.ll_weight
+        j.params, j.adam_m, j.adam_v = self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        j.grads = self.grads.data_ptr()
+        j.eps = self.eps.data_ptr() if self.eps is not None else None
+        j.seed = self.seed
+        j.loss_log = self.loss_log.data_ptr()
+        j.workspace = self._ws.data_ptr()
+        j.workspace_stride = self.ws_bytes
+        j.out_mu = self.out_mu.data_ptr() if self.out_mu is not None else None
+        j.out_logvar = self.out_logvar.data_ptr() if self.out_logvar is not None else None
+        j.out_z = self.out_z.data_ptr() if self.out_z is not None else None
+        for m, t in enumerate(self.tables):
+            md = j.mod[m]
+            md.D, md.Kx = t.D, t.Kx
+            md.x_f32, md.xb = t.x_f32.data_ptr(), t.xb.data_ptr()
+            self.layout.fill_modality(md, m)
+            md.out_loc = self.out_loc[m].data_ptr() if self.out_loc[m] is not None else None
+            md.out_sqerr = self.out_sqerr[m].data_ptr() if self.out_sqerr[m] is not None else None
+            md.out_rowdev = self.out_rowdev[m].data_ptr() if self.out_rowdev[m] is not None else None
+        _lib.check(_lib.load().nm_validate_job(C.byref(j)), "nm_validate_job")
+        return j
+
+    # -- state_dict interchange (reference key names) --------------------------------------------
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().cpu().clone() for k, v in self.layout.unflatten(self.params).items()}
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor]):
+        self.params.copy_(self.layout.flatten(state, device=self.device))
+
+    def grads_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().cpu().clone() for k, v in self.layout.unflatten(self.grads).items()}
+
+    def adam_dicts(self):
+        m = {k: v.detach().cpu().clone() for k, v in self.layout.unflatten(self.adam_m).items()}
+        v = {k: v.detach().cpu().clone() for k, v in self.layout.unflatten(self.adam_v).items()}
+        return m, v
+
+    @property
+    def batches_per_epoch(self) -> int:
+        return math.ceil(self.tables[0].N / BATCH)
+
+
+class JobSet:
+    """Device array of job descriptors = the unit one launch runs (one workgroup per job)."""
+
+    def __init__(self, jobs: Sequence[Job]):
+        if not jobs:
+            raise ValueError("empty job set")
+        self.jobs = list(jobs)
+        self.device = jobs[0].device
+        self.lib = _lib.load()
+        self._dev = None
+        self._n_tiles = 1
+
+    def _upload(self, n_tiles: int = 1):
+        for j in self.jobs:
+            j._ensure_workspace(n_tiles)
+        arr = (_lib.NmJob * len(self.jobs))(*[j.struct() for j in self.jobs])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._dev = host.to(self.device)
+        return self._dev.data_ptr()
+
+    def _launch(self, step0, steps_per_tile, n_tiles, flags, scalar_tr=False):
+        ptr = self._upload(n_tiles)
+        fn = self.lib.nm_launch_scalar_tr if scalar_tr else self.lib.nm_launch
+        _lib.check(fn(ptr, len(self.jobs), int(step0), int(steps_per_tile), int(n_tiles), int(flags),
+                      _stream_ptr(self.device)), "nm_launch")
+
+    def train(self, n_steps: int, scalar_tr: bool = False):
+        """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam)."""
+        step0 = self.jobs[0].step
+        if any(j.step != step0 for j in self.jobs):
+            raise ValueError("jobs of one set must be at the same step")
+        self._launch(step0, n_steps, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM, scalar_tr)
+        for j in self.jobs:
+            j.step += n_steps
+            j.t += n_steps
+
+    def grads(self, step: Optional[int] = None, export: bool = True, scalar_tr: bool = False):
+        """forward + loss + backward for one step; gradients land in job.grads (no update)."""
+        s = self.jobs[0].step if step is None else step
+        flags = _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | (_lib.NM_F_EXPORT if export else 0)
+        self._launch(s, 1, 1, flags, scalar_tr)
+
+    def forward(self, tile0: int = 0, n_tiles: Optional[int] = None):
+        """forward-only over row tiles (one workgroup per (job, 256-row tile)); fills the exports."""
+        nt = self.jobs[0].tables[0].n_tiles if n_tiles is None else n_tiles
+        self._launch(tile0, 1, nt, _lib.NM_F_EXPORT)
+
+    def losses(self) -> torch.Tensor:
+        """[n_jobs, loss_cap, 8] on the host."""
+        return torch.stack([j.loss_log for j in self.jobs]).cpu()
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, t: int, lr=1e-4,
+              betas=(0.9, 0.999), eps=1e-8):
+    """Flat Adam on device buffers (nm_adam_step); t is the 1-based step count."""
+    lib = _lib.load()
+    _lib.check(lib.nm_adam_step(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), params.numel(),
+                                lr, betas[0], betas[1], eps, t, _stream_ptr(params.device)), "nm_adam_step")

@@ -1,0 +1,173 @@
+"""Model shape description and the flat fp32 parameter layout the HIP kernels address.
+
+Tensors keep the reference's ``state_dict`` names, shapes and order (cVAE.py:140-206,
+1087-1116), so ``load_state_dict``/``state_dict`` interchange weights with the reference.
+Each tensor starts on a 16-byte boundary of the flat buffer (vector loads in the kernels).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+ALIGN = 4   # floats
+
+
+@dataclass
+class ModelSpec:
+    """Constructor arguments of the reference model classes (cVAE.py:391-399, 1087-1095)."""
+    input_dims: Sequence[int]
+    hidden: Sequence[int]
+    latent: int
+    c_dim: int
+    non_linear: bool = True
+    kind: str = "multimodal"      # "single" = class cVAE, "multimodal" = cVAE_multimodal
+
+    @property
+    def M(self) -> int:
+        return len(self.input_dims)
+
+    def validate(self):
+        if not (1 <= self.M <= _lib.NM_MAX_MOD):
+            raise ValueError(f"modalities must be 1..{_lib.NM_MAX_MOD}, got {self.M}")
+        if not (1 <= len(self.hidden) <= _lib.NM_MAX_HID):
+            raise ValueError(f"hidden layers must be 1..{_lib.NM_MAX_HID}, got {len(self.hidden)}")
+        if any(h < 1 or h > _lib.NM_MAX_WIDTH for h in self.hidden):
+            raise ValueError(f"hidden widths must be 1..{_lib.NM_MAX_WIDTH}, got {list(self.hidden)}")
+        if not (1 <= self.latent <= _lib.NM_MAX_LATENT):
+            raise ValueError(f"latent_dim must be 1..{_lib.NM_MAX_LATENT}, got {self.latent}")
+        if self.latent + self.c_dim > _lib.NM_MAX_WIDTH:
+            raise ValueError(f"latent_dim + c_dim must be <= {_lib.NM_MAX_WIDTH}")
+
+    # encoder / decoder layer sizes exactly as the reference computes them
+    def enc_sizes(self, m: int) -> List[int]:
+        return [self.input_dims[m] + self.c_dim] + list(self.hidden) + [self.latent]      # cVAE.py:153
+
+    def dec_sizes(self, m: int) -> List[int]:
+        hd = (list(self.hidden) + [self.latent])[::-1]                                    # cVAE.py:183
+        sizes = hd + [self.input_dims[m]]
+        sizes[0] = hd[0] + self.c_dim                                                     # cVAE.py:188
+        return sizes
+
+    def enc_prefix(self, m: int) -> str:
+        return "encoder." if self.kind == "single" else f"encoder_list.{m}."
+
+    def dec_prefix(self, m: int) -> str:
+        return "decoder." if self.kind == "single" else f"decoder_list.{m}."
+
+
+def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(name, shape) in the reference's registration order."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    L = len(spec.hidden)
+
+    def enc(m):
+        p, s = spec.enc_prefix(m), spec.enc_sizes(m)
+        for i in range(L):
+            out.append((f"{p}encoder_layers.{i}.weight", (s[i + 1], s[i])))
+            out.append((f"{p}encoder_layers.{i}.bias", (s[i + 1],)))
+        for h in ("enc_mean_layer", "enc_logvar_layer"):
+            out.append((f"{p}{h}.weight", (s[-1], s[-2])))
+            out.append((f"{p}{h}.bias", (s[-1],)))
+
+    def dec(m):
+        p, s = spec.dec_prefix(m), spec.dec_sizes(m)
+        out.append((f"{p}logvar_out", (1, spec.input_dims[m])))
+        for i in range(L):
+            out.append((f"{p}decoder_layers.{i}.weight", (s[i + 1], s[i])))
+            out.append((f"{p}decoder_layers.{i}.bias", (s[i + 1],)))
+        out.append((f"{p}decoder_mean_layer.weight", (s[-1], s[-2])))
+        out.append((f"{p}decoder_mean_layer.bias", (s[-1],)))
+
+    if spec.kind == "single":
+        enc(0)
+        dec(0)
+    elif spec.kind == "multimodal":
+        for m in range(spec.M):
+            out.append((f"alpha_m_list.{m}", (1,)))
+        for m in range(spec.M):
+            enc(m)
+        for m in range(spec.M):
+            dec(m)
+    else:
+        raise ValueError(f"unknown model kind {spec.kind!r}")
+    return out
+
+
+class ParamLayout:
+    def __init__(self, spec: ModelSpec):
+        spec.validate()
+        self.spec = spec
+        self.names: List[str] = []
+        self.shapes: Dict[str, Tuple[int, ...]] = {}
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for name, shape in tensor_table(spec):
+            self.names.append(name)
+            self.shapes[name] = shape
+            self.offsets[name] = off
+            n = 1
+            for d in shape:
+                n *= d
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.n_params = sum(math.prod(s) for s in self.shapes.values())
+
+    def numel(self, name: str) -> int:
+        return math.prod(self.shapes[name])
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        return flat[o:o + self.numel(name)].view(self.shapes[name])
+
+    def unflatten(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {n: self.view(flat, n) for n in self.names}
+
+    def flatten(self, state: Dict[str, torch.Tensor], device=None) -> torch.Tensor:
+        flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        for n in self.names:
+            if n not in state:
+                raise KeyError(f"state_dict is missing {n!r}")
+            t = state[n]
+            if tuple(t.shape) != tuple(self.shapes[n]):
+                raise ValueError(f"{n}: expected shape {self.shapes[n]}, got {tuple(t.shape)}")
+            self.view(flat, n).copy_(t.to(torch.float32))
+        return flat
+
+    def init_reference_rule(self, seed: int = 42) -> Dict[str, torch.Tensor]:
+        """nn.Linear default init U(+-1/sqrt(fan_in)) for weight and bias, logvar_out = -3,
+        alpha ~ N(0,1)  (cVAE.py:155-159, 179, 190-194, 1106)."""
+        g = torch.Generator().manual_seed(seed)
+        out: Dict[str, torch.Tensor] = {}
+        for n in self.names:
+            shape = self.shapes[n]
+            if n.endswith("logvar_out"):
+                out[n] = torch.full(shape, -3.0)
+            elif n.startswith("alpha_m_list"):
+                out[n] = torch.randn(shape, generator=g)
+            elif n.endswith(".weight"):
+                bound = 1.0 / math.sqrt(shape[1])
+                out[n] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            else:
+                fan_in = self.shapes[n[:-4] + "weight"][1]
+                bound = 1.0 / math.sqrt(fan_in)
+                out[n] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        return out
+
+    def fill_modality(self, md: "_lib.NmModality", m: int):
+        spec, o = self.spec, self.offsets
+        ep, dp = spec.enc_prefix(m), spec.dec_prefix(m)
+        for i in range(len(spec.hidden)):
+            md.enc_w[i] = o[f"{ep}encoder_layers.{i}.weight"]
+            md.enc_b[i] = o[f"{ep}encoder_layers.{i}.bias"]
+            md.dec_w[i] = o[f"{dp}decoder_layers.{i}.weight"]
+            md.dec_b[i] = o[f"{dp}decoder_layers.{i}.bias"]
+        md.mu_w, md.mu_b = o[f"{ep}enc_mean_layer.weight"], o[f"{ep}enc_mean_layer.bias"]
+        md.lv_w, md.lv_b = o[f"{ep}enc_logvar_layer.weight"], o[f"{ep}enc_logvar_layer.bias"]
+        md.logvar_out = o[f"{dp}logvar_out"]
+        md.out_w, md.out_b = o[f"{dp}decoder_mean_layer.weight"], o[f"{dp}decoder_mean_layer.bias"]
+        md.alpha = o.get(f"alpha_m_list.{m}", -1)

@@ -1,0 +1,97 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/nmhip.h
+declares, and its host-only helpers behave (no compute calls: there is no GPU here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+import multi_modal_normative_modeling_amd as nm
+from multi_modal_normative_modeling_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not _lib.LIB_PATH.exists():
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    header = (ROOT / "include" / "nmhip.h").read_text()
+    declared = set(re.findall(r"\b(nm_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+
+
+def test_abi_struct_sizes_match(lib):
+    sj, sm = C.c_int64(0), C.c_int64(0)
+    assert lib.nm_abi_sizes(C.byref(sj), C.byref(sm)) == 0
+    assert sj.value == C.sizeof(_lib.NmJob)
+    assert sm.value == C.sizeof(_lib.NmModality)
+
+
+def _probe(M=1, L=2, Z=10, C_=29, H=(110, 110), D=379):
+    j = _lib.NmJob()
+    j.M, j.L, j.Z, j.C = M, L, Z, C_
+    for i, h in enumerate(H):
+        j.H[i] = h
+    for m in range(min(M, _lib.NM_MAX_MOD)):
+        j.mod[m].D = D
+        j.mod[m].Kx = (D + C_ + 1 + 31) // 32 * 32
+    return j
+
+
+def test_validate_job_limits(lib):
+    assert lib.nm_validate_job(C.byref(_probe())) == 0
+    assert lib.nm_validate_job(C.byref(_probe(M=5))) == -2
+    assert lib.nm_validate_job(C.byref(_probe(L=4, H=(8, 8, 8)))) == -3
+    assert lib.nm_validate_job(C.byref(_probe(H=(128, 110)))) == -4
+    assert lib.nm_validate_job(C.byref(_probe(Z=65))) == -5
+    assert lib.nm_validate_job(C.byref(_probe(Z=64, C_=64))) == -6
+    bad = _probe()
+    bad.mod[0].Kx = 400
+    assert lib.nm_validate_job(C.byref(bad)) == -7
+    assert b"Kx" in lib.nm_status_string(-7)
+
+
+def test_workspace_bytes(lib):
+    w1 = lib.nm_workspace_bytes(C.byref(_probe()))
+    w3 = lib.nm_workspace_bytes(C.byref(_probe(M=3)))
+    assert w1 > 0 and w3 > w1 and w1 % 256 == 0
+
+
+def test_param_layout_matches_reference_names():
+    from tests.golden_util import Golden
+    for name in ("mm3_gpoe", "cfgA_T1w", "mm1_h1"):
+        g = Golden(name)
+        lay = nm.ParamLayout(nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim))
+        w = g.weights("w0")
+        assert lay.names == list(w.keys())              # reference state_dict() order
+        flat = lay.flatten(w)
+        for k, v in lay.unflatten(flat).items():
+            assert tuple(v.shape) == tuple(w[k].shape)
+            assert (v == w[k]).all()
+        assert all(o % 4 == 0 for o in lay.offsets.values())
+    g = Golden("cfgA_T1w")
+    assert nm.ParamLayout(nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim)).n_params == 118479
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.NmError):
+        nm.Table(torch.zeros(4, 3), torch.zeros(4, 2))
+
+
+def test_spec_limits_raise():
+    with pytest.raises(ValueError):
+        nm.ParamLayout(nm.ModelSpec([10], [200], 5, 2))
+    with pytest.raises(ValueError):
+        nm.ParamLayout(nm.ModelSpec([10] * 5, [20], 5, 2))
