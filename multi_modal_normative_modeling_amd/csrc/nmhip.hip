@@ -983,17 +983,16 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   for (int i = c.tid; i < 2 * ROWS * LDP / 2; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
-  double b1p = J->beta1_pow, b2p = J->beta2_pow;
   const int s_begin = step0 + blockIdx.y * steps_per_tile;
   for (int s = s_begin; s < s_begin + steps_per_tile; ++s) {
     int b = s % nb;
     c.row0 = b * ROWS;
     c.nrows = min(ROWS, J->n_rows - c.row0);
     c.inv_b = 1.0f / (float)c.nrows;
-    b1p *= (double)J->beta1;
-    b2p *= (double)J->beta2;
-    c.step_size = (float)((double)J->lr / (1.0 - b1p));
-    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2p));
+    // bias corrections in double, as torch.optim.Adam computes them on the host
+    const double tt = (double)(J->adam_t + (int64_t)(s - s_begin) + 1);
+    c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
+    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
     run_step<SCALAR_TR>(c, s);
     __syncthreads();
   }

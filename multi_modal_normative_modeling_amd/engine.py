@@ -165,8 +165,7 @@ class Job:
         j.non_linear = 1 if s.non_linear else 0
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
         j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
-        j.beta1_pow = self.betas[0] ** self.t
-        j.beta2_pow = self.betas[1] ** self.t
+        j.adam_t = self.t
         j.kl_weight, j.ll_weight = self.kl_weight, self.ll_weight
         j.params, j.adam_m, j.adam_v = self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
         j.grads = self.grads.data_ptr()

@@ -224,6 +224,52 @@ def init_params(spec: Spec, seed: int = 42) -> Dict[str, torch.Tensor]:
 
 
 # ----------------------------------------------------------------------------------------
+# operand-rounding mode
+# ----------------------------------------------------------------------------------------
+# The HIP path is specified (BASELINE.json north_star) to run every Linear as a bf16 MFMA GEMM
+# with fp32 accumulation.  "fp32" below is the reference's own arithmetic; "bf16" restates the
+# SAME algorithm with the GEMM operands (activations, weights, and in backward the incoming
+# deltas) rounded to bfloat16 -- everything else (bias add, activation, NLL, KL, fusion, Adam)
+# stays fp32.  LeakyReLU makes gradients discontinuous in the pre-activations, so an fp32-vs-bf16
+# comparison of gradients sees isolated sign flips; HIP-vs-"bf16" is the tight elementwise check,
+# HIP-vs-"fp32"/golden carries the 1e-4 reconstruction-loss bound.
+_OPERANDS = "fp32"
+
+
+def set_operand_rounding(mode: str):
+    global _OPERANDS
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(mode)
+    _OPERANDS = mode
+
+
+def _bf(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearBf16(torch.autograd.Function):
+    """y = bf16(a) @ bf16(W)^T + b with fp32 accumulation; backward rounds the incoming delta
+    to bf16 once and uses it for dgrad, wgrad and the bias gradient (ones-column of the wgrad)."""
+
+    @staticmethod
+    def forward(ctx, a, W, b):
+        ctx.save_for_backward(a, W)
+        return _bf(a) @ _bf(W).T + b
+
+    @staticmethod
+    def backward(ctx, go):
+        a, W = ctx.saved_tensors
+        gb = _bf(go)
+        return gb @ _bf(W), gb.T @ _bf(a), gb.sum(0)
+
+
+def linear(a, W, b):
+    if _OPERANDS == "bf16":
+        return _LinearBf16.apply(a, W, b)
+    return torch.nn.functional.linear(a, W, b)
+
+
+# ----------------------------------------------------------------------------------------
 # A1 / A2  encoder, decoder      (cVAE.py:140-172, 174-206)
 # ----------------------------------------------------------------------------------------
 def _act(h: torch.Tensor, non_linear: bool) -> torch.Tensor:
@@ -236,10 +282,9 @@ def encoder_fwd(P, spec: Spec, m: int, x: torch.Tensor, c: torch.Tensor):
     p = _enc_prefix(spec, m)
     h = torch.cat((x, c.to(x.dtype)), dim=1)
     for i in range(len(spec.hidden)):
-        h = _act(torch.nn.functional.linear(h, P[f"{p}encoder_layers.{i}.weight"],
-                                            P[f"{p}encoder_layers.{i}.bias"]), spec.non_linear)
-    mu = torch.nn.functional.linear(h, P[f"{p}enc_mean_layer.weight"], P[f"{p}enc_mean_layer.bias"])
-    logvar = torch.nn.functional.linear(h, P[f"{p}enc_logvar_layer.weight"], P[f"{p}enc_logvar_layer.bias"])
+        h = _act(linear(h, P[f"{p}encoder_layers.{i}.weight"], P[f"{p}encoder_layers.{i}.bias"]), spec.non_linear)
+    mu = linear(h, P[f"{p}enc_mean_layer.weight"], P[f"{p}enc_mean_layer.bias"])
+    logvar = linear(h, P[f"{p}enc_logvar_layer.weight"], P[f"{p}enc_logvar_layer.bias"])
     return mu, logvar
 
 
@@ -248,9 +293,8 @@ def decoder_fwd(P, spec: Spec, m: int, z: torch.Tensor, c: torch.Tensor, bank: s
     p = _dec_prefix(spec, m, bank)
     h = torch.cat((z, c.reshape(-1, spec.c_dim).to(z.dtype)), dim=1)
     for i in range(len(spec.hidden)):
-        h = _act(torch.nn.functional.linear(h, P[f"{p}decoder_layers.{i}.weight"],
-                                            P[f"{p}decoder_layers.{i}.bias"]), spec.non_linear)
-    loc = torch.nn.functional.linear(h, P[f"{p}decoder_mean_layer.weight"], P[f"{p}decoder_mean_layer.bias"])
+        h = _act(linear(h, P[f"{p}decoder_layers.{i}.weight"], P[f"{p}decoder_layers.{i}.bias"]), spec.non_linear)
+    loc = linear(h, P[f"{p}decoder_mean_layer.weight"], P[f"{p}decoder_mean_layer.bias"])
     scale = P[f"{p}logvar_out"].exp().pow(0.5)
     return loc, scale
 
