@@ -82,7 +82,7 @@ typedef struct nm_job {
   int32_t loss_cap;       /* rows of loss_log; step s writes row s % loss_cap            */
   int32_t eps_cap;        /* steps held by eps; step s reads block s % eps_cap           */
   float   lr, beta1, beta2, adam_eps;
-  int64_t adam_t;         /* optimizer steps already taken (bias correction uses t+1..) */
+  int64_t adam_off;       /* optimizer step count of data step s is adam_off + s + 1     */
   float   kl_weight;      /* d total / d KL   (= M for cVAE_multimodal, cVAE.py:1189-1195) */
   float   ll_weight;      /* d total / d (-LL_m)                                          */
   float*  params;         /* flat fp32 parameters                                        */

@@ -48,7 +48,7 @@ class NmJob(C.Structure):
         ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32),
         ("loss_cap", C.c_int32), ("eps_cap", C.c_int32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("adam_t", C.c_int64),
+        ("adam_off", C.c_int64),
         ("kl_weight", C.c_float), ("ll_weight", C.c_float),
         ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("grads", C.c_void_p),
         ("eps", C.c_void_p), ("seed", C.c_uint64),

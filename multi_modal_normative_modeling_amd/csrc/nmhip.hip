@@ -990,7 +990,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     c.nrows = min(ROWS, J->n_rows - c.row0);
     c.inv_b = 1.0f / (float)c.nrows;
     // bias corrections in double, as torch.optim.Adam computes them on the host
-    const double tt = (double)(J->adam_t + (int64_t)(s - s_begin) + 1);
+    const double tt = (double)(J->adam_off + (int64_t)s + 1);
     c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
     run_step<SCALAR_TR>(c, s);

@@ -108,6 +108,7 @@ class Job:
         self.eps_cap = 1
         self._ws = None
         self._ws_tiles = 0
+        self._version = 0                # bumped whenever the descriptor would change
         self._ensure_workspace(n_tiles_ws)
         # optional exports
         self.out_mu = self.out_logvar = self.out_z = None
@@ -125,9 +126,15 @@ class Job:
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
+        self._version += 1
+
+    def touch(self):
+        """Call after changing tables / step / t / hyper-parameters by hand: forces a descriptor re-upload."""
+        self._version += 1
 
     def set_eps(self, eps: Optional[torch.Tensor]):
         """Explicit reparameterisation draws [n_steps, 256, Z] (parity mode); None = in-kernel generator."""
+        self._version += 1
         if eps is None:
             self.eps, self.eps_cap = None, 1
             return
@@ -144,6 +151,7 @@ class Job:
     def enable_exports(self, loc=True, sqerr=True, rowdev=True, latent=True):
         ra = self.tables[0].rows_alloc
         Z = self.spec.latent
+        self._version += 1
         if latent:
             self.out_mu = torch.zeros(ra, Z, device=self.device)
             self.out_logvar = torch.zeros(ra, Z, device=self.device)
@@ -165,7 +173,7 @@ class Job:
         j.non_linear = 1 if s.non_linear else 0
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
         j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
-        j.adam_t = self.t
+        j.adam_off = self.t - self.step
         j.kl_weight, j.ll_weight = self.kl_weight, self.ll_weight
         j.params, j.adam_m, j.adam_v = self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
         j.grads = self.grads.data_ptr()
@@ -218,14 +226,19 @@ class JobSet:
         self.device = jobs[0].device
         self.lib = _lib.load()
         self._dev = None
-        self._n_tiles = 1
+        self._sig = None
 
     def _upload(self, n_tiles: int = 1):
+        """Descriptor array on the device; rebuilt only when a job's descriptor changed (the
+        optimizer step count rides on adam_off = t - step, constant while both advance)."""
         for j in self.jobs:
             j._ensure_workspace(n_tiles)
-        arr = (_lib.NmJob * len(self.jobs))(*[j.struct() for j in self.jobs])
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self._dev = host.to(self.device)
+        sig = tuple((j._version, j.t - j.step) for j in self.jobs)
+        if self._dev is None or sig != self._sig:
+            arr = (_lib.NmJob * len(self.jobs))(*[j.struct() for j in self.jobs])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._dev = host.to(self.device)
+            self._sig = sig
         return self._dev.data_ptr()
 
     def _launch(self, step0, steps_per_tile, n_tiles, flags, scalar_tr=False):

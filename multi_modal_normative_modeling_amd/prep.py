@@ -1,0 +1,135 @@
+"""Input preparation that sits immediately before the hot path,
+restated in numpy: RobustScaler, rank-quantile one-hot covariates, k-fold ids, and the
+build-owned synthetic ROI tables of SURVEY.md section 8(d).
+
+Reference call sites: multimodal_kfold_train_cvae_supervised.py:101-114 (scaler + one-hot),
+utils.py:73-93 / ..._regression.py:51 (KFold(shuffle=True, random_state=42)),
+early_fusion_modalities.py:23-32 + utils.py:717-724 (modality-major early-fusion columns).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+HCP_MODALITIES = ["T1w_sMRI", "T2w_sMRI", "fMRI"]          # utils.py:731-755 order for HCPimage
+EARLY_FUSION = "early_fusion_modalities_HCPimage"
+
+
+def robust_scaler_fit(x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """sklearn RobustScaler(): center = median, scale = IQR (25..75, linear interpolation); a zero
+    IQR scales by 1 (sklearn _handle_zeros_in_scale)."""
+    x = np.asarray(x, dtype=np.float64)
+    center = np.nanmedian(x, axis=0)
+    q = np.nanpercentile(x, [25.0, 75.0], axis=0)
+    scale = q[1] - q[0]
+    scale = np.where(scale < 10 * np.finfo(np.float64).eps, 1.0, scale)
+    return center, scale
+
+
+def robust_scaler_transform(x: np.ndarray, center: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    return (np.asarray(x, dtype=np.float64) - center) / scale
+
+
+def rank_first(col: np.ndarray) -> np.ndarray:
+    """pandas Series.rank(method='first'): 1-based ranks, ties broken by order of appearance."""
+    order = np.argsort(np.asarray(col), kind="stable")
+    ranks = np.empty(len(col), dtype=np.float64)
+    ranks[order] = np.arange(1, len(col) + 1, dtype=np.float64)
+    return ranks
+
+
+def qcut_rank_bins(col: np.ndarray, q: int) -> np.ndarray:
+    """pd.qcut(col.rank(method='first'), q, labels=range(q)) (..._supervised.py:107-112):
+    equal-count bins of the sort order; bin edges are the linear-interpolated quantiles of the
+    ranks 1..n, intervals are right-closed and the first one includes its left edge."""
+    r = rank_first(col)
+    n = len(r)
+    # pandas computes the edges as np.percentile(ranks, linspace(0,1,q+1)*100): use the same call so
+    # that an edge landing on an integer rank rounds the same way (bit-exact bins)
+    edges = np.percentile(np.arange(1, n + 1, dtype=np.float64), np.linspace(0, 1, q + 1) * 100)
+    bins = np.searchsorted(edges, r, side="left") - 1
+    bins[r <= edges[0]] = 0
+    return np.clip(bins, 0, q - 1).astype(np.int64)
+
+
+def one_hot_covariates(age: np.ndarray, gender: np.ndarray, age_bins: int = 27, gender_bins: int = 2) -> np.ndarray:
+    """np.concatenate((np.eye(27)[AGE_bins], np.eye(2)[PTGENDER_bins]), axis=1).astype('float32')
+    (..._supervised.py:107-126) -> c [N, 29]."""
+    a = qcut_rank_bins(age, age_bins)
+    s = qcut_rank_bins(gender, gender_bins)
+    return np.concatenate((np.eye(age_bins)[a], np.eye(gender_bins)[s]), axis=1).astype(np.float32)
+
+
+def kfold_indices(n: int, n_splits: int, seed: int = 42) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """sklearn KFold(n_splits, shuffle=True, random_state=seed).split(range(n)):
+    indices = arange(n) shuffled by RandomState(seed); the first n % n_splits folds get one extra
+    sample; test fold = consecutive slice of the shuffled indices; train = the rest, ascending."""
+    idx = np.arange(n)
+    rng = np.random.RandomState(seed)
+    rng.shuffle(idx)
+    sizes = np.full(n_splits, n // n_splits, dtype=int)
+    sizes[: n % n_splits] += 1
+    out, cur = [], 0
+    for s in sizes:
+        test = idx[cur:cur + s]
+        mask = np.zeros(n, dtype=bool)
+        mask[test] = True
+        out.append((np.arange(n)[~mask], np.arange(n)[mask]))
+        cur += s
+    return out
+
+
+def early_fusion(tables: Dict[str, np.ndarray], order: Sequence[str]) -> np.ndarray:
+    """Column-concatenate modality tables modality-major in `order` (early_fusion_modalities.py:23-32)."""
+    return np.concatenate([tables[m] for m in order], axis=1)
+
+
+@dataclass
+class SyntheticCohort:
+    iid: np.ndarray                   # ascending 6-digit ids
+    age: np.ndarray
+    gender: np.ndarray
+    dia: np.ndarray                   # 1 = healthy control (utils.py:770-771)
+    fi: np.ndarray
+    x: Dict[str, np.ndarray]          # modality -> float64 [N, D]
+
+
+def synthetic_cohort(n: int = 1280, d: int = 379, modalities: Sequence[str] = HCP_MODALITIES,
+                     seed: int = 20250418) -> SyntheticCohort:
+    """Synthetic ROI tables of SURVEY.md section 8(d): X_m = (s a_m + E_m) diag(g_m) + o_m with an
+    8-factor subject structure, per-ROI log-normal gain and offset; 5% of subjects (DIA = 0) get
+    +1.5 g on 40 random ROIs."""
+    rng = np.random.default_rng(seed)
+    s = rng.standard_normal((n, 8))
+    dia = np.ones(n, dtype=np.int64)
+    dia[rng.choice(n, size=max(1, n // 20), replace=False)] = 0
+    x = {}
+    for m in modalities:
+        a = rng.standard_normal((8, d))
+        e = rng.standard_normal((n, d))
+        g = rng.lognormal(0.0, 0.5, size=d)
+        o = rng.normal(0.0, 2.0, size=d)
+        xm = (s @ a + e) * g + o
+        rois = rng.choice(d, size=min(40, d), replace=False)
+        xm[np.ix_(dia == 0, rois)] += 1.5 * g[rois]
+        x[m] = xm
+    age = rng.integers(22, 37, size=n).astype(np.float64)
+    gender = rng.integers(0, 2, size=n).astype(np.float64)
+    fi = rng.normal(100.0, 15.0, size=n)
+    iid = np.arange(100001, 100001 + n, dtype=np.int64)
+    return SyntheticCohort(iid=iid, age=age, gender=gender, dia=dia, fi=fi, x=x)
+
+
+def fold_train_tables(cohort: SyntheticCohort, modalities: Sequence[str], train_idx: np.ndarray):
+    """Per-fold training inputs exactly as the train script prepares them: RobustScaler fit on
+    the fold's train rows, one-hot covariates binned on the same rows."""
+    xs = []
+    for m in modalities:
+        src = cohort.x[m] if m in cohort.x else early_fusion(cohort.x, HCP_MODALITIES)
+        tr = src[train_idx]
+        center, scale = robust_scaler_fit(tr)
+        xs.append(robust_scaler_transform(tr, center, scale).astype(np.float32))
+    c = one_hot_covariates(cohort.age[train_idx], cohort.gender[train_idx])
+    return xs, c

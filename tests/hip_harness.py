@@ -30,6 +30,7 @@ def swap_batch(job: nm.Job, g: Golden, step: int):
     job.tables = [nm.Table(xes[m], c, DEV) for m in range(g.M)]
     job.set_eps(g.t("eps")[step])
     job.step = 0
+    job.touch()
 
 
 def oracle_step0(g: Golden, kind="multimodal"):

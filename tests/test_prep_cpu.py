@@ -1,0 +1,63 @@
+"""Input-preparation restatements (prep.py) against the libraries the reference calls
+(sklearn RobustScaler / KFold, pandas qcut+rank) -- bit-exact on integer work."""
+import numpy as np
+import pandas as pd
+import pytest
+from sklearn.model_selection import KFold
+from sklearn.preprocessing import RobustScaler
+
+from multi_modal_normative_modeling_amd import prep
+
+
+def test_robust_scaler_matches_sklearn():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((257, 13)) * rng.lognormal(size=13) + 3.0
+    x[:, 5] = 2.0                                   # zero IQR column
+    c, s = prep.robust_scaler_fit(x)
+    ref = RobustScaler().fit(x)
+    np.testing.assert_allclose(c, ref.center_, rtol=0, atol=0)
+    np.testing.assert_allclose(s, ref.scale_, rtol=1e-15, atol=0)
+    np.testing.assert_allclose(prep.robust_scaler_transform(x, c, s), ref.transform(x), rtol=1e-14, atol=1e-14)
+
+
+@pytest.mark.parametrize("n,q", [(1024, 27), (1000, 27), (83, 27), (300, 2), (1277, 2), (57, 5)])
+def test_qcut_rank_bins_matches_pandas(n, q):
+    rng = np.random.default_rng(n + q)
+    col = rng.integers(22, 37, size=n).astype(float)        # heavy ties, as AGE / PTGENDER have
+    ref = pd.qcut(pd.Series(col).rank(method="first"), q=q, labels=list(range(q))).to_numpy().astype(np.int64)
+    got = prep.qcut_rank_bins(col, q)
+    assert np.array_equal(got, ref)
+
+
+def test_one_hot_covariates_layout():
+    rng = np.random.default_rng(3)
+    age = rng.integers(22, 37, size=500).astype(float)
+    sex = rng.integers(0, 2, size=500).astype(float)
+    c = prep.one_hot_covariates(age, sex)
+    assert c.shape == (500, 29) and c.dtype == np.float32
+    assert (c[:, :27].sum(1) == 1).all() and (c[:, 27:].sum(1) == 1).all()
+
+
+@pytest.mark.parametrize("n,k", [(1280, 5), (1064, 5), (597, 10)])
+def test_kfold_matches_sklearn(n, k):
+    ref = list(KFold(n_splits=k, shuffle=True, random_state=42).split(np.arange(n)))
+    got = prep.kfold_indices(n, k, 42)
+    for (a, b), (c, d) in zip(ref, got):
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+def test_early_fusion_is_modality_major():
+    t = {"T1w_sMRI": np.zeros((4, 3)), "T2w_sMRI": np.ones((4, 2)), "fMRI": np.full((4, 2), 2.0)}
+    f = prep.early_fusion(t, prep.HCP_MODALITIES)
+    assert f.shape == (4, 7)
+    assert (f[0] == np.array([0, 0, 0, 1, 1, 2, 2])).all()
+
+
+def test_synthetic_cohort_shapes_and_determinism():
+    a = prep.synthetic_cohort(n=320, d=37)
+    b = prep.synthetic_cohort(n=320, d=37)
+    assert list(a.x.keys()) == prep.HCP_MODALITIES
+    assert all(v.shape == (320, 37) for v in a.x.values())
+    assert all(np.array_equal(a.x[m], b.x[m]) for m in a.x)
+    assert (np.diff(a.iid) > 0).all()
+    assert (a.dia == 0).sum() == 16
