@@ -45,7 +45,8 @@ enum {
   NM_F_BACKWARD = 1,   /* run the backward pass                                        */
   NM_F_ADAM     = 2,   /* apply Adam inside the weight-gradient epilogues             */
   NM_F_GRADS    = 4,   /* store gradients to job.grads (parameter layout)             */
-  NM_F_EXPORT   = 8    /* store mu / logvar / z / loc / squared residual per row      */
+  NM_F_EXPORT   = 8,   /* store mu / logvar / z / loc / squared residual per row      */
+  NM_F_PROFILE  = 16   /* workgroup (0,0) accumulates per-phase shader-clock cycles   */
 };
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the
@@ -149,6 +150,9 @@ int nm_abi_sizes(int64_t* sizeof_job, int64_t* sizeof_modality);
 /* nm_launch with the scalar transposing LDS loader (validates ds_read_b64_tr_b16). */
 int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles,
                         int flags, void* stream);
+
+/* NM_F_PROFILE read-out: 32 per-phase cycle counters of workgroup (0,0); reset != 0 clears them. */
+int nm_prof_read(unsigned long long* out32, int reset);
 
 const char* nm_status_string(int status);
 int nm_version(void);

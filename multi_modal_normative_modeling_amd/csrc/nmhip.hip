@@ -44,8 +44,20 @@ constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // 16-byte copies (builtin vector: address-space safe)
+
+// explicit global-address-space pointer types (see asg())
+#define GAS __attribute__((address_space(1)))
+typedef GAS float* gf32;
+typedef const GAS float* gcf32;
+typedef GAS __bf16* gbf16;
+typedef const GAS __bf16* gcbf16;
+
+// Phase timers (NM_F_PROFILE): shader-clock cycles of workgroup (0,0), thread 0, accumulated per phase.
+__device__ unsigned long long nm_prof_cycles[32];
 
 struct Ctx {
+  unsigned long long t_last;
   const nm_job_t* job;
   __bf16* P;
   __bf16* Q;
@@ -60,7 +72,7 @@ struct Ctx {
   // Adam scalars of the current step
   float step_size;   // lr / (1 - beta1^t)
   float inv_bc2_sqrt;
-  char* ws;          // workspace of this tile
+  GAS char* ws;      // workspace of this tile
 };
 
 __host__ __device__ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
@@ -90,18 +102,53 @@ __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
 }
 
 // ---- small helpers ---------------------------------------------------------------------------
-__device__ inline float lrelu(float v, bool nl) { return (nl && v < 0.f) ? v * SLOPE : v; }
+enum { PH_ENC_L0 = 0, PH_ENC_REST, PH_HEADS, PH_LATENT, PH_DEC_ZC, PH_DEC_HID, PH_OUT_GEMM, PH_OUT_DLV, PH_OUT_DGRAD,
+       PH_OUT_WGRAD, PH_NLL_RED, PH_DEC_FINISH, PH_DEC_LOAD, PH_DEC_DGRAD, PH_DEC_WGRAD, PH_DEC_DELTA, PH_ALPHA,
+       PH_ENCB_PREP, PH_ENCB_HEADS_DGRAD, PH_ENCB_HEADS_WGRAD, PH_ENCB_LOAD, PH_ENCB_DGRAD, PH_ENCB_WGRAD,
+       PH_ENCB_DELTA, PH_ENCB_L0_WGRAD, PH_COUNT };
+__device__ __forceinline__ void prof(Ctx& c, int phase) {
+  if ((c.flags & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    unsigned long long t = clock64();
+    nm_prof_cycles[phase] += t - c.t_last;
+    c.t_last = t;
+  }
+}
+// Re-derive the lane/wave indices from an opaque copy of threadIdx.x.  Without this the compiler
+// hoists every per-lane LDS/global address of every phase out of the persistent step loop and then
+// spills hundreds of them; re-deriving per phase keeps live ranges phase-local.  The wave index goes
+// through readfirstlane so that wave-level work splits compile to scalar branches.
+__device__ __forceinline__ void relaunder(Ctx& c) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  c.tid = t;
+  c.lane = t & 63;
+  int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  c.wave = w;
+  c.wm = w >> 2;
+  c.wn = w & 3;
+  c.g = c.lane >> 4;
+  c.c16 = c.lane & 15;
+}
 
-__device__ inline unsigned lds_addr(const void* p) {
+// Pointers read out of the job descriptor are generic to the compiler; routing them through an
+// explicit global-address-space pointer type lets it emit global_* (saddr + 32-bit offset), not flat_*.
+template <class T>
+__device__ __forceinline__ GAS T* asg(T* p) {
+  return (GAS T*)p;
+}
+
+__device__ __forceinline__ float lrelu(float v, bool nl) { return (nl && v < 0.f) ? v * SLOPE : v; }
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-__device__ inline f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // A-operand fragment of a row-major bf16 LDS tile: lane holds buf[row][k .. k+7]
-__device__ inline bf16x8 lds_frag(const __bf16* buf, int ld, int row, int k) {
+__device__ __forceinline__ bf16x8 lds_frag(const __bf16* buf, int ld, int row, int k) {
   return *reinterpret_cast<const bf16x8*>(buf + row * ld + k);
 }
 
@@ -110,7 +157,7 @@ __device__ inline bf16x8 lds_frag(const __bf16* buf, int ld, int row, int k) {
 // within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane
 // i receives column i of the four rows (cdna_hip_programming.md T10).  EXEC is all ones here.
 struct TrAddr { unsigned a; };
-__device__ inline unsigned tr_addr(const __bf16* buf, int ld, int r0, int c0, int lane) {
+__device__ __forceinline__ unsigned tr_addr(const __bf16* buf, int ld, int r0, int c0, int lane) {
   int i = lane & 15, g = lane >> 4;
   int q = i >> 2, p = i & 3;
   return lds_addr(buf + (r0 + 8 * g + q) * ld + c0 + 4 * p);
@@ -118,7 +165,7 @@ __device__ inline unsigned tr_addr(const __bf16* buf, int ld, int r0, int c0, in
 #define NM_TR_READ(dst, addr, OFF) \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
 
-__device__ inline bf16x8 join4(bf16x4 lo, bf16x4 hi) {
+__device__ __forceinline__ bf16x8 join4(bf16x4 lo, bf16x4 hi) {
   bf16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -126,7 +173,7 @@ __device__ inline bf16x8 join4(bf16x4 lo, bf16x4 hi) {
 }
 
 // Scalar reference form of the transposed fragment (unit tests compare the two).
-__device__ inline bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, int r0, int c0, int lane) {
+__device__ __forceinline__ bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, int r0, int c0, int lane) {
   int c = c0 + (lane & 15), g = lane >> 4;
   bf16x8 r;
 #pragma unroll
@@ -135,39 +182,40 @@ __device__ inline bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, int r0, i
 }
 
 // Forward weight fragment: W[n][k0 .. k0+7] (fp32, row-major [N][K]) -> bf16x8, zero outside.
-__device__ inline bf16x8 w_frag(const float* __restrict__ W, int N, int K, int n, int k0) {
+__device__ __forceinline__ bf16x8 w_frag(gcf32 W, int N, int K, int n, int k0) {
   bf16x8 r;
-  const float* src = W + (int64_t)n * K + k0;
-  if (n < N && k0 + 8 <= K && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-    const float4* p = reinterpret_cast<const float4*>(src);
-    float4 a = p[0], b = p[1];
-    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
-    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+  gcf32 src = W + (int64_t)n * K + k0;
+  if (n < N && k0 + 8 <= K && (((uintptr_t)src & 15) == 0)) {
+    const GAS f32x4* p = (const GAS f32x4*)src;
+    f32x4 a = p[0], b = p[1];
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
   } else {
+    // unconditional loads from clamped (always valid) addresses, then select: no branch, all 8 in flight
+    const int nc = min(n, N - 1);
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int k = k0 + j;
-      float v = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
-      r[j] = (__bf16)v;
-    }
+    for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)nc * K + min(k0 + j, K - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)((n < N && k0 + j < K) ? v[j] : 0.f);
   }
   return r;
 }
 
 // Dgrad weight fragment: W[n0 + j][k] for j = 0..7 (contraction over the OUTPUT index n).
-__device__ inline bf16x8 w_frag_t(const float* __restrict__ W, int N, int K, int n0, int k) {
+__device__ __forceinline__ bf16x8 w_frag_t(gcf32 W, int N, int K, int n0, int k) {
   bf16x8 r;
+  const int kc = min(k, K - 1);
+  float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int n = n0 + j;
-    float v = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
-    r[j] = (__bf16)v;
-  }
+  for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)min(n0 + j, N - 1) * K + kc];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)((n0 + j < N && k < K) ? v[j] : 0.f);
   return r;
 }
 
 // Block-wide sum; every thread gets the result.  Fixed summation order (bitwise reproducible).
-__device__ inline float block_sum(const Ctx& c, float v) {
+__device__ __forceinline__ float block_sum(const Ctx& c, float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
@@ -180,13 +228,13 @@ __device__ inline float block_sum(const Ctx& c, float v) {
 }
 
 // Counter-based standard normal for the in-kernel draw (eps == NULL): splitmix64 + Box-Muller.
-__device__ inline uint64_t splitmix64(uint64_t x) {
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-__device__ inline float randn_ctr(uint64_t seed, uint32_t step, uint32_t row, uint32_t z) {
+__device__ __forceinline__ float randn_ctr(uint64_t seed, uint32_t step, uint32_t row, uint32_t z) {
   uint64_t h = splitmix64(seed ^ ((uint64_t)step << 32) ^ ((uint64_t)row << 8) ^ z);
   uint64_t h2 = splitmix64(h);
   float u1 = ((uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1]
@@ -195,48 +243,79 @@ __device__ inline float randn_ctr(uint64_t seed, uint32_t step, uint32_t row, ui
 }
 
 // Gradient sink: optional store + Adam (torch.optim.Adam, cVAE.py:1111-1116).
-__device__ inline void apply_grad(const Ctx& c, int64_t idx, float g) {
+__device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g) {
   const nm_job_t* J = c.job;
-  if (c.flags & NM_F_GRADS) J->grads[idx] = g;
+  if (c.flags & NM_F_GRADS) asg(J->grads)[idx] = g;
   if (c.flags & NM_F_ADAM) {
-    float p = J->params[idx], m = J->adam_m[idx], v = J->adam_v[idx];
+    gf32 P_ = asg(J->params); gf32 M_ = asg(J->adam_m); gf32 V_ = asg(J->adam_v);
+    float p = P_[idx], m = M_[idx], v = V_[idx];
     m = m + (g - m) * (1.0f - J->beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
     v = v * J->beta2 + (1.0f - J->beta2) * g * g;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
     float denom = sqrtf(v) * c.inv_bc2_sqrt + J->adam_eps;
     p = p - c.step_size * (m / denom);
-    J->params[idx] = p; J->adam_m[idx] = m; J->adam_v[idx] = v;
+    P_[idx] = p; M_[idx] = m; V_[idx] = v;
+  }
+}
+
+// 4 gradient elements (one accumulator tile register group): loads first, then Adam, then stores
+__device__ __forceinline__ void apply_grad4(const Ctx& c, const int (&idx)[4], const bool (&ok)[4], const f32x4& g) {
+  const nm_job_t* J = c.job;
+  if (c.flags & NM_F_GRADS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ok[e]) asg(J->grads)[idx[e]] = g[e];
+  }
+  if (c.flags & NM_F_ADAM) {
+    float p[4], m[4], v[4];
+    gf32 P_ = asg(J->params);
+    gf32 M_ = asg(J->adam_m);
+    gf32 V_ = asg(J->adam_v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[e] = P_[idx[e]]; m[e] = M_[idx[e]]; v[e] = V_[idx[e]]; }
+    const float b1 = J->beta1, b2 = J->beta2, ae = J->adam_eps;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m[e] = m[e] + (g[e] - m[e]) * (1.0f - b1);
+      v[e] = v[e] * b2 + (1.0f - b2) * g[e] * g[e];
+      float denom = sqrtf(v[e]) * c.inv_bc2_sqrt + ae;
+      p[e] = p[e] - c.step_size * (m[e] / denom);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ok[e]) { P_[idx[e]] = p[e]; M_[idx[e]] = m[e]; V_[idx[e]] = v[e]; }
   }
 }
 
 // ---- cooperative copies ----------------------------------------------------------------------
 // global bf16 [256][PW] (saved activation) -> LDS [256][LDP]
-__device__ inline void load_act(const Ctx& c, __bf16* dst, const __bf16* src) {
+__device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src) {
   // 256 rows x 16 pieces of 16 B
   for (int p = c.tid; p < ROWS * (PW / 8); p += WG) {
     int row = p >> 4, seg = p & 15;
-    uint4 v = *reinterpret_cast<const uint4*>(src + row * PW + seg * 8);
-    *reinterpret_cast<uint4*>(dst + row * LDP + seg * 8) = v;
+    u32x4 v = *(const GAS u32x4*)(src + row * PW + seg * 8);
+    *reinterpret_cast<u32x4*>(dst + row * LDP + seg * 8) = v;
   }
 }
 
 // one 64-column chunk of the packed table xb into registers / into Q (pitch LDX)
-struct XStage { uint4 v[4]; };
-__device__ inline void xchunk_load(const Ctx& c, XStage& s, const uint16_t* xb, int Kx, int kc) {
+struct XStage { u32x4 v[4]; };
+__device__ __forceinline__ void xchunk_load(const Ctx& c, XStage& s, const GAS uint16_t* xb, int Kx, int kc) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int p = c.tid + i * WG;            // 2048 pieces of 16 B
     int row = p >> 3, seg = p & 7;
     int col = kc * XCH + seg * 8;
-    uint4 z = {0u, 0u, 0u, 0u};
-    s.v[i] = (col < Kx) ? *reinterpret_cast<const uint4*>(xb + (int64_t)(c.row0 + row) * Kx + col) : z;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4 ld = *(const GAS u32x4*)(xb + (int64_t)(c.row0 + row) * Kx + min(col, Kx - 8));
+    s.v[i] = (col < Kx) ? ld : z;
   }
 }
-__device__ inline void xchunk_store(const Ctx& c, const XStage& s, __bf16* Q) {
+__device__ __forceinline__ void xchunk_store(const Ctx& c, const XStage& s, __bf16* Q) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int p = c.tid + i * WG;
     int row = p >> 3, seg = p & 7;
-    *reinterpret_cast<uint4*>(Q + row * LDX + seg * 8) = s.v[i];
+    *reinterpret_cast<u32x4*>(Q + row * LDX + seg * 8) = s.v[i];
   }
 }
 
@@ -244,8 +323,10 @@ __device__ inline void xchunk_store(const Ctx& c, const XStage& s, __bf16* Q) {
 // out[r][n] = act(sum_k P[r][k] W[n][k] + b[n]), n < N; column N := 1 (ones column feeding the
 // next layer's bias gradient), columns (N, wpad(N)) := 0.  Optionally saved to `save` (bf16
 // [256][PW]) for the backward pass.
-__device__ void fwd_layer_inplace(const Ctx& c, const float* W, const float* b, int N, int K, bool act,
-                                  __bf16* save) {
+__device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 b, int N, int K, bool act,
+                                                  gbf16 save) {
+  Ctx c = cc;
+  relaunder(c);
   const int ksteps = wpad(K) / 32;
   const int ntn = wpad(N) / 16;
   f32x4 acc[8][2];
@@ -297,8 +378,10 @@ __device__ void fwd_layer_inplace(const Ctx& c, const float* W, const float* b, 
 }
 
 // ---- GEMM phase: first encoder layer, x streamed through Q in 64-column chunks ----------------
-__device__ void fwd_first_layer(const Ctx& c, const nm_modality_t& md, const float* W, const float* b, int N, int K,
-                                bool act, __bf16* save) {
+__device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality_t& md, gcf32 W, gcf32 b, int N, int K,
+                                                bool act, gbf16 save) {
+  Ctx c = cc;
+  relaunder(c);
   const int Kx = md.Kx;
   const int nch = (Kx + XCH - 1) / XCH;
   const int ntn = wpad(N) / 16;
@@ -311,11 +394,11 @@ __device__ void fwd_first_layer(const Ctx& c, const nm_modality_t& md, const flo
     for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
   }
   XStage st;
-  xchunk_load(c, st, md.xb, Kx, 0);
+  xchunk_load(c, st, asg(md.xb), Kx, 0);
   for (int kc = 0; kc < nch; ++kc) {
     xchunk_store(c, st, c.Q);
     __syncthreads();
-    if (kc + 1 < nch) xchunk_load(c, st, md.xb, Kx, kc + 1);
+    if (kc + 1 < nch) xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       int kg = kc * XCH + ks * 32;
@@ -356,8 +439,10 @@ __device__ void fwd_first_layer(const Ctx& c, const nm_modality_t& md, const flo
 }
 
 // ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
-__device__ void fwd_heads(const Ctx& c, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
-                          int Z, int K, float* mu_out, float* lv_out, int Zs) {
+__device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, gcf32 Wlv, gcf32 blv, int Z, int K,
+                                          gf32 mu_out, gf32 lv_out, int Zs) {
+  Ctx c = cc;
+  relaunder(c);
   const int ksteps = wpad(K) / 32;
   const int nzt = Zs / 16;
   for (int nt = c.wn; nt < nzt; nt += 4) {
@@ -392,8 +477,10 @@ __device__ void fwd_heads(const Ctx& c, const float* Wmu, const float* bmu, cons
 // ---- dgrad: acc[r][k] += sum_n P[r][n] W[n][k]  (contraction over P's columns) -----------------
 // k tiles {wn, wn+4} of wpad(K); nsteps = 32-wide steps over P's columns; n_base = index of P's
 // column 0 in W's row space.
-__device__ inline void dgrad_acc(const Ctx& c, f32x4 (&acc)[8][2], const __bf16* A, const float* W, int N, int K,
-                                 int nsteps, int n_base) {
+__device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[8][2], const __bf16* A, gcf32 W, int N, int K,
+                                          int nsteps, int n_base) {
+  Ctx c = cc;
+  relaunder(c);
   const int ntk = wpad(K) / 16;
   for (int s = 0; s < nsteps; ++s) {
     bf16x8 bf[2];
@@ -411,8 +498,10 @@ __device__ inline void dgrad_acc(const Ctx& c, f32x4 (&acc)[8][2], const __bf16*
 }
 
 // dgrad through the two encoder heads: P columns [0,Zs) = d mu, [Zs,2Zs) = d logvar
-__device__ inline void dgrad_heads(const Ctx& c, f32x4 (&acc)[8][2], const float* Wmu, const float* Wlv, int Z, int K,
-                                   int Zs) {
+__device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[8][2], gcf32 Wmu, gcf32 Wlv, int Z, int K,
+                                            int Zs) {
+  Ctx c = cc;
+  relaunder(c);
   const int ntk = wpad(K) / 16;
   const int nsteps = rup(2 * Zs, 32) / 32;
   for (int s = 0; s < nsteps; ++s) {
@@ -438,8 +527,10 @@ __device__ inline void dgrad_heads(const Ctx& c, f32x4 (&acc)[8][2], const float
 // weight W[n][k], k == K the bias b[n] (ones column), beyond: nothing.  Work unit = one n-tile x
 // up to four k-tiles, dealt round-robin to the 8 waves.
 template <bool SCALAR_TR>
-__device__ void wgrad_adam(const Ctx& c, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb, int N, int K,
+__device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb, int N, int K,
                            int k_base, int nkt, int64_t w_off, int64_t b_off) {
+  Ctx c = cc;
+  relaunder(c);
   const int ntn = (N + 15) / 16;
   const int kgroups = (nkt + 3) / 4;
   const int units = ntn * kgroups;
@@ -484,25 +575,30 @@ __device__ void wgrad_adam(const Ctx& c, const __bf16* A, int lda, int a_col0, c
         aa += a_step; ba += b_step;
       }
     }
+    // epilogue, one 16x16 tile at a time: its 4 elements' p, m, v loads are issued together
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       int kt = kg * 4 + t;
-      if (kt >= nkt) continue;
       int k = k_base + kt * 16 + c.c16;
+      int idx[4];
+      bool ok[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int n = nt * 16 + 4 * c.g + i;
-        if (n < N) {
-          if (k < K) apply_grad(c, w_off + (int64_t)n * K + k, acc[t][i]);
-          else if (k == K) apply_grad(c, b_off + n, acc[t][i]);
-        }
+        bool v = (kt < nkt) && (n < N) && (k <= K);
+        int64_t ix = (k < K) ? w_off + (int64_t)n * K + k : b_off + n;
+        ok[i] = v;
+        idx[i] = v ? (int)ix : 0;
       }
+      apply_grad4(c, idx, ok, acc[t]);
     }
   }
 }
 
 // P[r][k] = acc[r][k] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
-__device__ inline void finish_delta(const Ctx& c, const f32x4 (&acc)[8][2], const __bf16* src, int K, bool act) {
+__device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[8][2], const __bf16* src, int K, bool act) {
+  Ctx c = cc;
+  relaunder(c);
   const int ntk = wpad(K) / 16;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -524,91 +620,109 @@ __device__ inline void finish_delta(const Ctx& c, const f32x4 (&acc)[8][2], cons
   }
 }
 
-__device__ inline void zero_acc(f32x4 (&acc)[8][2]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[8][2]) {
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 }
 
 // ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
 struct Fuse { float mu, lv, var; };
-__device__ inline void softmax_alpha(const nm_job_t* J, float* al) {
+struct Lat { float mu[NM_MAX_MOD], lv[NM_MAX_MOD]; };     // always indexed by unrolled constants
+__device__ __forceinline__ void softmax_alpha(const nm_job_t* J, float (&al)[NM_MAX_MOD]) {
   float mx = -INFINITY;
-  for (int m = 0; m < J->M; ++m) mx = fmaxf(mx, J->params[J->mod[m].alpha]);
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m)
+    if (m < J->M) mx = fmaxf(mx, asg(J->params)[J->mod[m].alpha]);
   float s = 0.f;
-  for (int m = 0; m < J->M; ++m) { al[m] = expf(J->params[J->mod[m].alpha] - mx); s += al[m]; }
-  for (int m = 0; m < J->M; ++m) al[m] /= s;
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m) {
+    al[m] = (m < J->M) ? expf(asg(J->params)[J->mod[m].alpha] - mx) : 0.f;
+    s += al[m];
+  }
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m) al[m] /= s;
 }
-__device__ inline Fuse fuse_fwd(const nm_job_t* J, const float* mu, const float* lv, const float* al) {
+__device__ __forceinline__ Fuse fuse_fwd(const nm_job_t* J, const Lat& L, const float (&al)[NM_MAX_MOD]) {
   const int M = J->M;
   Fuse f;
-  if (M == 1 && J->single_bypass) { f.mu = mu[0]; f.var = expf(lv[0]); f.lv = logf(f.var); return f; }
-  int cb = J->combine;
-  if (cb == NM_COMBINE_POE || cb == NM_COMBINE_GPOE || cb == NM_COMBINE_MOPOE) {
-    float S = 0.f, Smu = 0.f;
-    for (int m = 0; m < M; ++m) {
-      float var = expf(lv[m]);
+  if (M == 1 && J->single_bypass) { f.mu = L.mu[0]; f.var = expf(L.lv[0]); f.lv = logf(f.var); return f; }
+  const int cb = J->combine;
+  float S = 0.f, Smu = 0.f, sm = 0.f, sv = 0.f;
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m) {
+    if (m < M) {
+      float var = expf(L.lv[m]);
       float w = (cb == NM_COMBINE_GPOE) ? al[m] / var : 1.0f / var;
-      S += w; Smu += mu[m] * w;
+      S += w; Smu += L.mu[m] * w;
+      sm += L.mu[m]; sv += var;
     }
+  }
+  if (cb == NM_COMBINE_MOE) { f.mu = sm / M; f.var = sv / M; }
+  else {
     f.mu = Smu / S; f.var = 1.0f / S;
-    if (cb == NM_COMBINE_MOPOE) {
-      float sm = f.mu, sv = f.var;
-      for (int m = 0; m < M; ++m) { sm += mu[m]; sv += expf(lv[m]); }
-      f.mu = sm / (M + 1); f.var = sv / (M + 1);
-    }
-  } else {   // MoE: uniform weights
-    float sm = 0.f, sv = 0.f;
-    for (int m = 0; m < M; ++m) { sm += mu[m]; sv += expf(lv[m]); }
-    f.mu = sm / M; f.var = sv / M;
+    if (cb == NM_COMBINE_MOPOE) { f.mu = (sm + f.mu) / (M + 1); f.var = (sv + f.var) / (M + 1); }
   }
   f.lv = logf(f.var);
   return f;
 }
-// backward of the fusion for expert m: (d mu_j, d lv_j) -> (d mu_m, d lv_m), and d alpha_m (gPoE)
-__device__ inline void fuse_bwd(const nm_job_t* J, const float* mu, const float* lv, const float* al, int m,
-                                float dmu_j, float dlv_j, float& dmu_m, float& dlv_m, float& dalpha_m) {
+// backward of the fusion: (d mu_j, d lv_j) -> (d mu_m, d lv_m) and d alpha_m (gPoE) for EVERY expert
+struct FuseGrad { float dmu[NM_MAX_MOD], dlv[NM_MAX_MOD], dal[NM_MAX_MOD]; };
+__device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, const float (&al)[NM_MAX_MOD], float dmu_j,
+                                             float dlv_j) {
   const int M = J->M;
-  dalpha_m = 0.f;
-  if (M == 1 && J->single_bypass) { dmu_m = dmu_j; dlv_m = dlv_j; return; }
-  int cb = J->combine;
+  FuseGrad G;
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m) { G.dmu[m] = 0.f; G.dlv[m] = 0.f; G.dal[m] = 0.f; }
+  if (M == 1 && J->single_bypass) { G.dmu[0] = dmu_j; G.dlv[0] = dlv_j; return G; }
+  const int cb = J->combine;
+  float S = 0.f, Smu = 0.f, sv = 0.f;
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m) {
+    if (m < M) {
+      float w = expf(-L.lv[m]) * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);
+      S += w; Smu += L.mu[m] * w;
+      sv += expf(L.lv[m]);
+    }
+  }
   if (cb == NM_COMBINE_MOE) {
-    float sv = 0.f;
-    for (int q = 0; q < M; ++q) sv += expf(lv[q]);
-    dmu_m = dmu_j / M;
-    dlv_m = dlv_j * expf(lv[m]) / sv;                 // d log(mean var) / d lv_m
-    return;
+#pragma unroll
+    for (int m = 0; m < NM_MAX_MOD; ++m)
+      if (m < M) { G.dmu[m] = dmu_j / M; G.dlv[m] = dlv_j * expf(L.lv[m]) / sv; }   // d log(mean var) / d lv_m
+    return G;
   }
-  // PoE family: precisions p_q (times alpha_q for gPoE)
-  float S = 0.f, Smu = 0.f;
-  for (int q = 0; q < M; ++q) {
-    float w = expf(-lv[q]) * ((cb == NM_COMBINE_GPOE) ? al[q] : 1.0f);
-    S += w; Smu += mu[q] * w;
-  }
-  float var_p = 1.0f / S, mu_p = Smu * var_p;
-  float pm = expf(-lv[m]);
-  float wm = pm * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);
-  float dmu_p = dmu_j, dlv_p = dlv_j;                 // gradients w.r.t. the PoE expert (mu_p, log var_p)
-  float extra_mu = 0.f, extra_lv = 0.f;
+  const float var_p = 1.0f / S, mu_p = Smu * var_p;
+  float dmu_p = dmu_j, dlv_p = dlv_j, e_mu = 0.f, e_lv = 0.f;    // e_*: direct MoE branch of MoPoE
   if (cb == NM_COMBINE_MOPOE) {
-    float sv = var_p;
-    for (int q = 0; q < M; ++q) sv += expf(lv[q]);
-    float var_j = sv / (M + 1);
+    float var_j = (sv + var_p) / (M + 1);
     dmu_p = dmu_j / (M + 1);
-    dlv_p = dlv_j * var_p / ((M + 1) * var_j);        // through var_p = exp(log var_p)
-    extra_mu = dmu_j / (M + 1);
-    extra_lv = dlv_j * expf(lv[m]) / ((M + 1) * var_j);
+    dlv_p = dlv_j * var_p / ((M + 1) * var_j);          // through var_p = exp(log var_p)
+    e_mu = dmu_j / (M + 1);
+    e_lv = dlv_j / ((M + 1) * var_j);
   }
-  float r = var_p * wm;                               // sigma^2 * p_m
-  dmu_m = dmu_p * r + extra_mu;
-  dlv_m = -dmu_p * r * (mu[m] - mu_p) + dlv_p * r + extra_lv;
-  if (cb == NM_COMBINE_GPOE) dalpha_m = dmu_p * var_p * pm * (mu[m] - mu_p) - dlv_p * var_p * pm;
+#pragma unroll
+  for (int m = 0; m < NM_MAX_MOD; ++m) {
+    if (m < M) {
+      float pm = expf(-L.lv[m]);
+      float r = var_p * pm * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);     // sigma^2 * p_m
+      G.dmu[m] = dmu_p * r + e_mu;
+      G.dlv[m] = -dmu_p * r * (L.mu[m] - mu_p) + dlv_p * r + e_lv * expf(L.lv[m]);
+      if (cb == NM_COMBINE_GPOE) G.dal[m] = dmu_p * var_p * pm * (L.mu[m] - mu_p) - dlv_p * var_p * pm;
+    }
+  }
+  return G;
+}
+__device__ __forceinline__ float pick(const float (&a)[NM_MAX_MOD], int m) {
+  float r = a[0];
+#pragma unroll
+  for (int q = 1; q < NM_MAX_MOD; ++q) r = (q == m) ? a[q] : r;
+  return r;
 }
 
 // ----------------------------------------------------------------------------------------------
 // The step: all phases for one tile of 256 rows.
 // ----------------------------------------------------------------------------------------------
 template <bool SCALAR_TR>
-__device__ void run_step(Ctx& c, int step) {
+__device__ __forceinline__ void run_step(Ctx& c, int step) {
   const nm_job_t* J = c.job;
   const int M = J->M, L = J->L, Z = J->Z, C = J->C;
   const bool nl = J->non_linear != 0;
@@ -616,42 +730,50 @@ __device__ void run_step(Ctx& c, int step) {
   const bool exportf = (c.flags & NM_F_EXPORT) != 0;
   const WsLayout wl = ws_layout(M, L, Z);
   const int Zs = wl.Zs;
-  float* ws_mu_m = reinterpret_cast<float*>(c.ws + wl.mu_m);
-  float* ws_lv_m = reinterpret_cast<float*>(c.ws + wl.lv_m);
-  float* ws_mu_j = reinterpret_cast<float*>(c.ws + wl.mu_j);
-  float* ws_lv_j = reinterpret_cast<float*>(c.ws + wl.lv_j);
-  float* ws_es = reinterpret_cast<float*>(c.ws + wl.es);
-  float* ws_dz = reinterpret_cast<float*>(c.ws + wl.dz);
-  __bf16* ws_enc = reinterpret_cast<__bf16*>(c.ws + wl.enc_act);
-  __bf16* ws_dec = reinterpret_cast<__bf16*>(c.ws + wl.dec_act);
-  const float* prm = J->params;
+  gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m);
+  gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m);
+  gf32 ws_mu_j = (gf32)(c.ws + wl.mu_j);
+  gf32 ws_lv_j = (gf32)(c.ws + wl.lv_j);
+  gf32 ws_es = (gf32)(c.ws + wl.es);
+  gf32 ws_dz = (gf32)(c.ws + wl.dz);
+  gbf16 ws_enc = (gbf16)(c.ws + wl.enc_act);
+  gbf16 ws_dec = (gbf16)(c.ws + wl.dec_act);
+  gcf32 prm = asg(J->params);
 
   // ================= encoders =================
   for (int m = 0; m < M; ++m) {
+    relaunder(c);
     const nm_modality_t& md = J->mod[m];
-    __bf16* save0 = bwd ? ws_enc + (int64_t)(m * L + 0) * ROWS * PW : nullptr;
+    gbf16 save0 = bwd ? ws_enc + (int64_t)(m * L + 0) * ROWS * PW : (gbf16)nullptr;
     fwd_first_layer(c, md, prm + md.enc_w[0], prm + md.enc_b[0], J->H[0], md.D + C, nl, save0);
+    prof(c, PH_ENC_L0);
     for (int e = 1; e < L; ++e) {
-      __bf16* sv = bwd ? ws_enc + (int64_t)(m * L + e) * ROWS * PW : nullptr;
+      gbf16 sv = bwd ? ws_enc + (int64_t)(m * L + e) * ROWS * PW : (gbf16)nullptr;
       fwd_layer_inplace(c, prm + md.enc_w[e], prm + md.enc_b[e], J->H[e], J->H[e - 1], nl, sv);
     }
+    prof(c, PH_ENC_REST);
     fwd_heads(c, prm + md.mu_w, prm + md.mu_b, prm + md.lv_w, prm + md.lv_b, Z, J->H[L - 1],
               ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs);
+    prof(c, PH_HEADS);
   }
 
   // ================= fusion + reparameterisation + KL =================
   float al[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
   if (J->combine == NM_COMBINE_GPOE && !(M == 1 && J->single_bypass)) softmax_alpha(J, al);
+  auto load_lat = [&](Lat& L, int r, int z) {
+#pragma unroll
+    for (int m = 0; m < NM_MAX_MOD; ++m) {
+      L.mu[m] = (m < M) ? ws_mu_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
+      L.lv[m] = (m < M) ? ws_lv_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
+    }
+  };
   float kl_part = 0.f;
   for (int e = c.tid; e < ROWS * Z; e += WG) {
     int r = e / Z, z = e - r * Z;
-    float mu[NM_MAX_MOD], lv[NM_MAX_MOD];
-    for (int m = 0; m < M; ++m) {
-      mu[m] = ws_mu_m[((int64_t)m * ROWS + r) * Zs + z];
-      lv[m] = ws_lv_m[((int64_t)m * ROWS + r) * Zs + z];
-    }
-    Fuse f = fuse_fwd(J, mu, lv, al);
-    float ep = J->eps ? J->eps[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + z]
+    Lat Lt;
+    load_lat(Lt, r, z);
+    Fuse f = fuse_fwd(J, Lt, al);
+    float ep = J->eps ? asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + z]
                       : randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)z);
     float es = ep * expf(0.5f * f.lv);
     float zz = f.mu + es;
@@ -663,17 +785,19 @@ __device__ void run_step(Ctx& c, int step) {
       kl_part += -0.5f * (1.0f + f.lv - f.mu * f.mu - expf(f.lv));
       if (exportf) {
         int64_t gr = (int64_t)(c.row0 + r) * Z + z;
-        if (J->out_mu) J->out_mu[gr] = f.mu;
-        if (J->out_logvar) J->out_logvar[gr] = f.lv;
-        if (J->out_z) J->out_z[gr] = zz;
+        if (J->out_mu) asg(J->out_mu)[gr] = f.mu;
+        if (J->out_logvar) asg(J->out_logvar)[gr] = f.lv;
+        if (J->out_z) asg(J->out_z)[gr] = zz;
       }
     }
   }
   float kl = block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
+  prof(c, PH_LATENT);
 
   // ================= decoders (forward, NLL, and the whole decoder backward) =================
-  float ll_m[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
+  float ll_sum = 0.f;
   for (int m = 0; m < M; ++m) {
+    relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int D = md.D;
     // --- build zc = [z | c | 1 | 0] in P ---
@@ -683,29 +807,32 @@ __device__ void run_step(Ctx& c, int step) {
       int r = e / wz, k = e - r * wz;
       float v;
       if (k < Z) v = ws_mu_j[r * Zs + k] + ws_es[r * Zs + k];
-      else if (k < Kd0) v = (float)reinterpret_cast<const __bf16*>(md.xb)[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
+      else if (k < Kd0) v = (float)((gcbf16)asg(md.xb))[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
       else v = (k == Kd0) ? 1.0f : 0.0f;
       c.P[r * LDP + k] = (__bf16)v;
     }
     __syncthreads();
+    prof(c, PH_DEC_ZC);
     // --- hidden decoder layers ---
     for (int d = 0; d < L; ++d) {
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
-      __bf16* sv = (bwd && d < L - 1) ? ws_dec + (int64_t)d * ROWS * PW : nullptr;
+      gbf16 sv = (bwd && d < L - 1) ? ws_dec + (int64_t)d * ROWS * PW : (gbf16)nullptr;
       fwd_layer_inplace(c, prm + md.dec_w[d], prm + md.dec_b[d], Nout, Kin, nl, sv);
     }
+    prof(c, PH_DEC_HID);
     // --- output layer in chunks of 128 ROI columns, fused with NLL, its backward and Adam ---
     const int Hl = J->H[0];                       // width feeding the output layer
-    const float* Wo = prm + md.out_w;
-    const float* bo = prm + md.out_b;
-    const float* lvo = prm + md.logvar_out;
+    gcf32 Wo = prm + md.out_w;
+    gcf32 bo = prm + md.out_b;
+    gcf32 lvo = prm + md.logvar_out;
     f32x4 accg[8][2];
     zero_acc(accg);
     float nll_part = 0.f;
     if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
     const int nchunks = (D + PW - 1) / PW;
     for (int ch = 0; ch < nchunks; ++ch) {
+      relaunder(c);
       const int d0 = ch * PW;
       const int valid = min(PW, D - d0);
       if (c.tid < PW) c.colacc[c.tid] = 0.f;
@@ -741,8 +868,15 @@ __device__ void run_step(Ctx& c, int step) {
           float s = dv ? lvo[d] : 0.f;
           float inv = expf(-s);
           float colsum = 0.f;
+          // all 32 inputs of this column first (rows are always inside the zero-padded table)
+          const int dcl = min(d, D - 1);
 #pragma unroll
           for (int mt = 0; mt < 8; ++mt) {
+            // the 4 inputs of this row tile first (rows are always inside the zero-padded table)
+            float xin[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              xin[i] = asg(md.x_f32)[(int64_t)(c.row0 + c.wm * 128 + mt * 16 + 4 * c.g + i) * D + dcl];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
@@ -750,7 +884,7 @@ __device__ void run_step(Ctx& c, int step) {
               float delta = 0.f;
               if (ok) {
                 int64_t gi = (int64_t)(c.row0 + r) * D + d;
-                float x = md.x_f32[gi];
+                float x = xin[i];
                 float xh = acc[mt][t][i];
                 float diff = xh - x;
                 float q = diff * diff * inv;
@@ -758,8 +892,8 @@ __device__ void run_step(Ctx& c, int step) {
                 colsum += 0.5f - 0.5f * q;
                 delta = J->ll_weight * diff * inv * c.inv_b;
                 if (exportf) {
-                  if (md.out_loc) md.out_loc[gi] = xh;
-                  if (md.out_sqerr) md.out_sqerr[gi] = diff * diff;
+                  if (md.out_loc) asg(md.out_loc)[gi] = xh;
+                  if (md.out_sqerr) asg(md.out_sqerr)[gi] = diff * diff;
                   if (md.out_rowdev) atomicAdd(&c.rowacc[r], diff * diff);
                 }
               }
@@ -775,21 +909,29 @@ __device__ void run_step(Ctx& c, int step) {
       }
       if (!bwd) continue;
       __syncthreads();
+      prof(c, PH_OUT_GEMM);
       // d logvar_out for this chunk
       if (c.tid < valid) apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b);
       // dgrad into the last hidden activation: accg[r][k] += sum_d Q[r][d] Wo[d0 + d][k]
+      prof(c, PH_OUT_DLV);
       dgrad_acc(c, accg, c.Q, Wo, D, Hl, rup(valid, 32) / 32, d0);
       __syncthreads();                              // all reads of the old Wo are done
+      prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
       wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, (Hl + 1 + 15) / 16,
                             md.out_w + (int64_t)d0 * Hl, md.out_b + d0);
       __syncthreads();
+      prof(c, PH_OUT_WGRAD);
     }
     float nll = block_sum(c, nll_part);
-    ll_m[m] = -nll * c.inv_b;                       // compute_ll: sum over ROI, mean over rows
+    const float ll_this = -nll * c.inv_b;           // compute_ll: sum over ROI, mean over rows
+    ll_sum += ll_this;
+    if (c.tid == 0 && J->loss_log)
+      asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_LL_M + m] = ll_this;
+    prof(c, PH_NLL_RED);
     if (exportf && md.out_rowdev) {
       __syncthreads();
-      for (int r = c.tid; r < c.nrows; r += WG) md.out_rowdev[c.row0 + r] = c.rowacc[r] / (float)D;
+      for (int r = c.tid; r < c.nrows; r += WG) asg(md.out_rowdev)[c.row0 + r] = c.rowacc[r] / (float)D;
     }
     if (!bwd) { __syncthreads(); continue; }
 
@@ -797,7 +939,9 @@ __device__ void run_step(Ctx& c, int step) {
     // state: P = activation g_{L-1}, accg = pre-mask delta of g_{L-1}
     finish_delta(c, accg, c.P, Hl, nl);             // mask source is P itself (same element)
     __syncthreads();
+    prof(c, PH_DEC_FINISH);
     for (int d = L - 1; d >= 0; --d) {
+      relaunder(c);
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
       // Q <- input activation of decoder layer d
@@ -807,7 +951,7 @@ __device__ void run_step(Ctx& c, int step) {
           int r = e / wz, k = e - r * wz;
           float v;
           if (k < Z) v = ws_mu_j[r * Zs + k] + ws_es[r * Zs + k];
-          else if (k < Kd0) v = (float)reinterpret_cast<const __bf16*>(md.xb)[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
+          else if (k < Kd0) v = (float)((gcbf16)asg(md.xb))[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
           else v = (k == Kd0) ? 1.0f : 0.0f;
           c.Q[r * LDP + k] = (__bf16)v;
         }
@@ -815,12 +959,15 @@ __device__ void run_step(Ctx& c, int step) {
         load_act(c, c.Q, ws_dec + (int64_t)(d - 1) * ROWS * PW);
       }
       __syncthreads();
+      prof(c, PH_DEC_LOAD);
       f32x4 acc[8][2];
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.dec_w[d], Nout, Kin, wpad(Nout) / 32, 0);
       __syncthreads();                              // old weights fully read
+      prof(c, PH_DEC_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, (Kin + 1 + 15) / 16, md.dec_w[d], md.dec_b[d]);
       __syncthreads();
+      prof(c, PH_DEC_WGRAD);
       if (d > 0) {
         finish_delta(c, acc, c.Q, Kin, nl);
       } else {
@@ -843,22 +990,21 @@ __device__ void run_step(Ctx& c, int step) {
         }
       }
       __syncthreads();
+      prof(c, PH_DEC_DELTA);
     }
   }
 
   // ================= loss log =================
   {
-    float ll_sum = 0.f;
-    for (int m = 0; m < M; ++m) ll_sum += ll_m[m];
     if (c.tid == 0 && J->loss_log) {
-      float* row = J->loss_log + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
+      gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
       row[NM_LOSS_KL] = J->kl_weight * kl;
       row[NM_LOSS_LL] = ll_sum;
       row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
-      for (int m = 0; m < M; ++m) row[NM_LOSS_LL_M + m] = ll_m[m];
     }
   }
   if (!bwd) return;
+  prof(c, PH_ALPHA);
 
   // ================= fusion backward: alpha gradients (gPoE) =================
   const bool fused = !(M == 1 && J->single_bypass);
@@ -867,32 +1013,32 @@ __device__ void run_step(Ctx& c, int step) {
     float dal[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
     for (int e = c.tid; e < c.nrows * Z; e += WG) {
       int r = e / Z, z = e - r * Z;
-      float mu[NM_MAX_MOD], lv[NM_MAX_MOD];
-      for (int m = 0; m < M; ++m) {
-        mu[m] = ws_mu_m[((int64_t)m * ROWS + r) * Zs + z];
-        lv[m] = ws_lv_m[((int64_t)m * ROWS + r) * Zs + z];
-      }
+      Lat Lt;
+      load_lat(Lt, r, z);
       float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
       float dmu_j = dz + klw * mj;
       float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
-      for (int m = 0; m < M; ++m) {
-        float a, b, da;
-        fuse_bwd(J, mu, lv, al, m, dmu_j, dlv_j, a, b, da);
-        dal[m] += da;
-      }
+      FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+#pragma unroll
+      for (int m = 0; m < NM_MAX_MOD; ++m) dal[m] += G.dal[m];
     }
     float tot[NM_MAX_MOD];
-    for (int m = 0; m < M; ++m) tot[m] = block_sum(c, dal[m]);
+#pragma unroll
+    for (int m = 0; m < NM_MAX_MOD; ++m) tot[m] = block_sum(c, dal[m]);
     if (c.tid == 0) {
       float dot = 0.f;
-      for (int m = 0; m < M; ++m) dot += al[m] * tot[m];
-      for (int m = 0; m < M; ++m) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
+#pragma unroll
+      for (int m = 0; m < NM_MAX_MOD; ++m) dot += al[m] * tot[m];
+#pragma unroll
+      for (int m = 0; m < NM_MAX_MOD; ++m)
+        if (m < M) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
     }
     __syncthreads();
   }
 
   // ================= encoders, backward =================
   for (int m = 0; m < M; ++m) {
+    relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int Hh = J->H[L - 1];
     const int whp = rup(2 * Zs, 32);
@@ -902,57 +1048,62 @@ __device__ void run_step(Ctx& c, int step) {
       int z = (k < Zs) ? k : k - Zs;
       float v = 0.f;
       if (z < Z && k < 2 * Zs && r < c.nrows) {
-        float mu[NM_MAX_MOD], lv[NM_MAX_MOD];
-        for (int q = 0; q < M; ++q) {
-          mu[q] = ws_mu_m[((int64_t)q * ROWS + r) * Zs + z];
-          lv[q] = ws_lv_m[((int64_t)q * ROWS + r) * Zs + z];
-        }
+        Lat Lt;
+        load_lat(Lt, r, z);
         float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
         float dmu_j = dz + klw * mj;
         float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
-        float a, b, da;
-        fuse_bwd(J, mu, lv, al, m, dmu_j, dlv_j, a, b, da);
-        v = (k < Zs) ? a : b;
+        FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+        v = (k < Zs) ? pick(G.dmu, m) : pick(G.dlv, m);
       }
       c.P[r * LDP + k] = (__bf16)v;
     }
     load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW);
     __syncthreads();
+    prof(c, PH_ENCB_PREP);
     f32x4 acc[8][2];
     zero_acc(acc);
     dgrad_heads(c, acc, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
     __syncthreads();
+    prof(c, PH_ENCB_HEADS_DGRAD);
     wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, (Hh + 1 + 15) / 16, md.mu_w, md.mu_b);
     wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, (Hh + 1 + 15) / 16, md.lv_w, md.lv_b);
     __syncthreads();
+    prof(c, PH_ENCB_HEADS_WGRAD);
     finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
     __syncthreads();
+    prof(c, PH_ENCB_DELTA);
     for (int e = L - 1; e >= 1; --e) {
       int Kin = J->H[e - 1], Nout = J->H[e];
       load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW);
       __syncthreads();
+      prof(c, PH_ENCB_LOAD);
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.enc_w[e], Nout, Kin, wpad(Nout) / 32, 0);
       __syncthreads();
+      prof(c, PH_ENCB_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, (Kin + 1 + 15) / 16, md.enc_w[e], md.enc_b[e]);
       __syncthreads();
+      prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
       __syncthreads();
+      prof(c, PH_ENCB_DELTA);
     }
     // first encoder layer: dW[n][k] = sum_r P[r][n] xc[r][k], x streamed through Q
     {
       const int Kx = md.Kx, K0 = md.D + C, N0 = J->H[0];
       const int nch = (Kx + XCH - 1) / XCH;
       XStage st;
-      xchunk_load(c, st, md.xb, Kx, 0);
+      xchunk_load(c, st, asg(md.xb), Kx, 0);
       for (int kc = 0; kc < nch; ++kc) {
         xchunk_store(c, st, c.Q);
         __syncthreads();
-        if (kc + 1 < nch) xchunk_load(c, st, md.xb, Kx, kc + 1);
+        if (kc + 1 < nch) xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
         int cols = min(XCH, Kx - kc * XCH);
         wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDX, N0, K0, kc * XCH, cols / 16, md.enc_w[0], md.enc_b[0]);
         __syncthreads();
       }
+      prof(c, PH_ENCB_L0_WGRAD);
     }
   }
 }
@@ -970,15 +1121,9 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   c.red = reinterpret_cast<float*>(c.Q + ROWS * LDP);
   c.colacc = c.red + 64;
   c.rowacc = c.colacc + 128;
-  c.tid = threadIdx.x;
-  c.lane = c.tid & 63;
-  c.wave = c.tid >> 6;
-  c.wm = c.wave >> 2;
-  c.wn = c.wave & 3;
-  c.g = c.lane >> 4;
-  c.c16 = c.lane & 15;
+  relaunder(c);
   c.flags = flags;
-  c.ws = reinterpret_cast<char*>(J->workspace) + (int64_t)blockIdx.y * J->workspace_stride;
+  c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   // zero LDS once: padded columns are multiplied by zero weights and must stay finite
   for (int i = c.tid; i < 2 * ROWS * LDP / 2; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
@@ -993,6 +1138,8 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     const double tt = (double)(J->adam_off + (int64_t)s + 1);
     c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+    if (flags & 16) c.t_last = clock64();
+    relaunder(c);
     run_step<SCALAR_TR>(c, s);
     __syncthreads();
   }
@@ -1056,7 +1203,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
     if (mode == 0) {
       for (int ks = 0; ks < rup(K, 32) / 32; ++ks) {
         bf16x8 bf[2];
-        for (int t = 0; t < 2; ++t) bf[t] = w_frag(B, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+        for (int t = 0; t < 2; ++t) bf[t] = w_frag(asg(B), N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
           bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
@@ -1066,7 +1213,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
       }
     } else {
       // emulate wpad semantics: dgrad_acc masks k tiles with wpad(K)
-      dgrad_acc(c, acc, c.P, B, N, K, rup(N, 32) / 32, 0);
+      dgrad_acc(c, acc, c.P, asg(B), N, K, rup(N, 32) / 32, 0);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1134,6 +1281,18 @@ constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (64 + 128 + 256) * 4;
 extern "C" {
 
 int nm_version(void) { return 1; }
+
+/* phase profile (NM_F_PROFILE = 16): read / reset the per-phase shader-clock accumulators */
+int nm_prof_read(unsigned long long* out32, int reset) {
+  if (!out32) return -1;
+  hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(nm_prof_cycles), sizeof(unsigned long long) * 32);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(nm_prof_cycles), z, sizeof(z));
+  }
+  return (int)e;
+}
 
 int nm_abi_sizes(int64_t* sizeof_job, int64_t* sizeof_modality) {
   if (!sizeof_job || !sizeof_modality) return -1;

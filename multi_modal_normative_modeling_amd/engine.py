@@ -247,12 +247,13 @@ class JobSet:
         _lib.check(fn(ptr, len(self.jobs), int(step0), int(steps_per_tile), int(n_tiles), int(flags),
                       _stream_ptr(self.device)), "nm_launch")
 
-    def train(self, n_steps: int, scalar_tr: bool = False):
+    def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False):
         """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam)."""
         step0 = self.jobs[0].step
         if any(j.step != step0 for j in self.jobs):
             raise ValueError("jobs of one set must be at the same step")
-        self._launch(step0, n_steps, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM, scalar_tr)
+        flags = _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | (_lib.NM_F_PROFILE if profile else 0)
+        self._launch(step0, n_steps, 1, flags, scalar_tr)
         for j in self.jobs:
             j.step += n_steps
             j.t += n_steps
