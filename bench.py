@@ -144,7 +144,7 @@ def main():
         batches = []
         for b in range(jobs[0].batches_per_epoch):
             lo, hi = b * 256, min(N, (b + 1) * 256)
-            xes = [t.x_f32[lo:hi].cpu() for t in jobs[0].tables]
+            xes = [t.x_f32[lo:hi, :t.D].cpu().contiguous() for t in jobs[0].tables]
             c = jobs[0].tables[0].xb[lo:hi, jobs[0].tables[0].D:jobs[0].tables[0].D + spec.c_dim].float().cpu()
             batches.append((xes, [c.long()] * len(xes)))
         sps, n = time_cpu_steps(stepper, batches, budget_s=args.cpu_budget)

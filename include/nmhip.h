@@ -55,7 +55,8 @@ enum {
 typedef struct nm_modality {
   int32_t D;              /* ROI features of this modality                               */
   int32_t Kx;             /* row pitch of xb in elements: multiple of 32, >= D + C + 1   */
-  const float*    x_f32;  /* [rows_alloc][D]   fp32 inputs (residual / NLL side)         */
+  int32_t x_pitch;        /* row pitch of x_f32 in floats: multiple of 4, >= D           */
+  const float*    x_f32;  /* [rows_alloc][x_pitch] fp32 inputs (residual / NLL side)     */
   const uint16_t* xb;     /* [rows_alloc][Kx]  bf16: x | c | 1 | 0...   (MFMA operand)   */
   int64_t enc_w[NM_MAX_HID], enc_b[NM_MAX_HID];   /* encoder_layers.{i}.weight/.bias      */
   int64_t mu_w, mu_b, lv_w, lv_b;                 /* enc_mean_layer / enc_logvar_layer    */
@@ -134,9 +135,10 @@ int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t 
                  float lr, float beta1, float beta2, float eps, int64_t t, void* stream);
 
 /* Build the bf16 operand table xb[rows_alloc][Kx] = x | c | 1 | 0 from fp32 x [n_rows][D] and
- * fp32 c [n_rows][C]; rows >= n_rows are zero-filled.  Also zero-pads x_f32_out if given. */
+ * fp32 c [n_rows][C]; rows >= n_rows are zero-filled.  x_f32_out [rows_alloc][x_pitch] receives the
+ * zero-padded fp32 copy (x_pitch = D rounded up to a multiple of 4). */
 int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx,
-                  uint16_t* xb, float* x_f32_out, void* stream);
+                  uint16_t* xb, float* x_f32_out, int x_pitch, void* stream);
 
 /* Debug / unit-test entry: C[M][N] = A[M][K] * B[N][K]^T through the kernel's own fragment
  * loaders.  mode 0: A row-major via LDS, B fp32 weights (forward form); mode 1: dgrad form

@@ -30,7 +30,7 @@ LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 
 class NmModality(C.Structure):
     _fields_ = [
-        ("D", C.c_int32), ("Kx", C.c_int32),
+        ("D", C.c_int32), ("Kx", C.c_int32), ("x_pitch", C.c_int32),
         ("x_f32", C.c_void_p), ("xb", C.c_void_p),
         ("enc_w", C.c_int64 * NM_MAX_HID), ("enc_b", C.c_int64 * NM_MAX_HID),
         ("mu_w", C.c_int64), ("mu_b", C.c_int64), ("lv_w", C.c_int64), ("lv_b", C.c_int64),
@@ -90,7 +90,7 @@ def load():
     lib.nm_grads.argtypes = [vp, i32, i32, vp]
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
-    lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     lib.nm_prof_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
     sj, sm = i64(0), i64(0)

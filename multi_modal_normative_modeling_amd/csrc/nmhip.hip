@@ -9,15 +9,18 @@
 //   LDS  P [256][136] bf16 : the running activation / delta of the layer chain (updated in place)
 //        Q [256][136] bf16 : the other operand of the current layer (saved activation, staged
 //                            x-chunk, or delta chunk of the decoder output layer)
-//   HBM/L2  fp32 parameters + Adam moments in the reference's own tensor layout; weights are read
-//           straight into MFMA B-fragments (fp32 -> bf16 in registers), each element once per
-//           pass; Adam runs in the weight-gradient epilogue on the accumulator tile.
+//        S [4352] fp32     : staging slab of a weight-gradient tile group for the coalesced Adam sweep
+//   HBM/L2  fp32 parameters + Adam moments in the reference's own tensor layout.  Weights are read
+//           straight into MFMA fragments (fp32 -> bf16 in registers), each element once per pass;
+//           Adam streams p/m/v as contiguous 16-byte-per-lane sweeps over each gradient slab.
 //   workspace (L2-resident): fp32 latent statistics, bf16 activations saved for backward.
 //
-// Every contraction is a v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The three GEMM forms:
-//   forward  out[r][n] = sum_k P[r][k] W[n][k]        A = ds_read_b128 of P rows, B = W rows
-//   dgrad    din[r][k] = sum_n P[r][n] W[n][k]        A = ds_read_b128 of P rows, B = W columns
-//   wgrad    dW[n][k]  = sum_r P[r][n] Q[r][k]        A, B = ds_read_b64_tr_b16 (transposing read)
+// Every contraction is a v_mfma_f32_16x16x32_bf16 (fp32 accumulate), issued "transposed":
+// the FEATURE index of the result lives in the accumulator registers (4 consecutive features per
+// lane) and the batch ROW on the lane, so every epilogue touches 8 or 16 contiguous bytes:
+//   forward  out[r][n] = sum_k P[r][k] W[n][k]      A = W rows (global),   B = ds_read_b128 of P rows
+//   dgrad    din[r][k] = sum_n P[r][n] W[n][k]      A = W columns (global), B = ds_read_b128 of P rows
+//   wgrad    dW[n][k]  = sum_r P[r][n] Q[r][k]      A, B = ds_read_b64_tr_b16 (transposing LDS read)
 //
 // Reference semantics restated here (paths relative to the reference checkout):
 //   Encoder/Decoder            cVAE.py:140-206        expert fusion  cVAE.py:986-1083, 1144-1164
@@ -38,6 +41,7 @@ constexpr int PW = 128;          // padded feature width held in P/Q
 constexpr int LDP = 136;         // P/Q row pitch (elements): +8 breaks the 256-B bank period
 constexpr int LDX = 72;          // row pitch of a staged 64-column x chunk inside Q
 constexpr int XCH = 64;          // columns per staged x chunk
+constexpr int STAGE_FLOATS = 4352;   // 32 x (128 + 4) or 64 x (64 + 4) fp32
 constexpr float SLOPE = 0.01f;   // F.leaky_relu default (cVAE.py:167,203)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
@@ -61,6 +65,7 @@ struct Ctx {
   const nm_job_t* job;
   __bf16* P;
   __bf16* Q;
+  float* stage;      // [STAGE_FLOATS] gradient slab
   float* red;        // [64] reduction scratch
   float* colacc;     // [128] per-column accumulators
   float* rowacc;     // [256] per-row accumulators
@@ -107,12 +112,13 @@ enum { PH_ENC_L0 = 0, PH_ENC_REST, PH_HEADS, PH_LATENT, PH_DEC_ZC, PH_DEC_HID, P
        PH_ENCB_PREP, PH_ENCB_HEADS_DGRAD, PH_ENCB_HEADS_WGRAD, PH_ENCB_LOAD, PH_ENCB_DGRAD, PH_ENCB_WGRAD,
        PH_ENCB_DELTA, PH_ENCB_L0_WGRAD, PH_COUNT };
 __device__ __forceinline__ void prof(Ctx& c, int phase) {
-  if ((c.flags & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     unsigned long long t = clock64();
     nm_prof_cycles[phase] += t - c.t_last;
     c.t_last = t;
   }
 }
+
 // Re-derive the lane/wave indices from an opaque copy of threadIdx.x.  Without this the compiler
 // hoists every per-lane LDS/global address of every phase out of the persistent step loop and then
 // spills hundreds of them; re-deriving per phase keeps live ranges phase-local.  The wave index goes
@@ -143,11 +149,21 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
+// exact a / b for 0 <= a < 2^22, 0 < b: float reciprocal + one-step fix (no integer division)
+__device__ __forceinline__ int idiv(int a, int b, float rb) {
+  int q = (int)((float)a * rb);
+  q += ((q + 1) * b <= a) ? 1 : 0;
+  q -= (q * b > a) ? 1 : 0;
+  return q;
+}
+
+// D = A * B + C with A = 16 features x 32 k, B = 32 k x 16 rows: lane (c16, g) supplies
+// A[feature c16][k 8g..8g+7] and B[k 8g..8g+7][row c16], and receives D[feature 4g+i][row c16].
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// A-operand fragment of a row-major bf16 LDS tile: lane holds buf[row][k .. k+7]
+// fragment of a row-major bf16 LDS tile: lane holds buf[row][k .. k+7]
 __device__ __forceinline__ bf16x8 lds_frag(const __bf16* buf, int ld, int row, int k) {
   return *reinterpret_cast<const bf16x8*>(buf + row * ld + k);
 }
@@ -156,7 +172,6 @@ __device__ __forceinline__ bf16x8 lds_frag(const __bf16* buf, int ld, int row, i
 // operand of a contraction over the ROW index of a row-major tile.  Two ds_read_b64_tr_b16:
 // within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane
 // i receives column i of the four rows (cdna_hip_programming.md T10).  EXEC is all ones here.
-struct TrAddr { unsigned a; };
 __device__ __forceinline__ unsigned tr_addr(const __bf16* buf, int ld, int r0, int c0, int lane) {
   int i = lane & 15, g = lane >> 4;
   int q = i >> 2, p = i & 3;
@@ -185,11 +200,18 @@ __device__ __forceinline__ bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, 
 __device__ __forceinline__ bf16x8 w_frag(gcf32 W, int N, int K, int n, int k0) {
   bf16x8 r;
   gcf32 src = W + (int64_t)n * K + k0;
-  if (n < N && k0 + 8 <= K && (((uintptr_t)src & 15) == 0)) {
+  const bool inside = n < N && k0 + 8 <= K;
+  if (inside && (((uintptr_t)src & 15) == 0)) {
     const GAS f32x4* p = (const GAS f32x4*)src;
     f32x4 a = p[0], b = p[1];
     r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
     r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  } else if (inside && (((uintptr_t)src & 7) == 0)) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const GAS f32x2* p = (const GAS f32x2*)src;
+    f32x2 a = p[0], b = p[1], c2 = p[2], d = p[3];
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)b[0]; r[3] = (__bf16)b[1];
+    r[4] = (__bf16)c2[0]; r[5] = (__bf16)c2[1]; r[6] = (__bf16)d[0]; r[7] = (__bf16)d[1];
   } else {
     // unconditional loads from clamped (always valid) addresses, then select: no branch, all 8 in flight
     const int nc = min(n, N - 1);
@@ -242,58 +264,65 @@ __device__ __forceinline__ float randn_ctr(uint64_t seed, uint32_t step, uint32_
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// Gradient sink: optional store + Adam (torch.optim.Adam, cVAE.py:1111-1116).
+// ---- Adam (torch.optim.Adam as configured at cVAE.py:1111-1116) -------------------------------
+struct AdamK { float b1, b2, eps, step_size, inv_bc2_sqrt; };
+__device__ __forceinline__ AdamK adam_consts(const Ctx& c) {
+  const nm_job_t* J = c.job;
+  return AdamK{J->beta1, J->beta2, J->adam_eps, c.step_size, c.inv_bc2_sqrt};
+}
+__device__ __forceinline__ void adam1(const AdamK& a, float g, float& p, float& m, float& v) {
+  m = m + (g - m) * (1.0f - a.b1);                    // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.b2 + (1.0f - a.b2) * g * g;               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+  float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+  p = p - a.step_size * (m / denom);
+}
+
+// scalar gradient sink (a handful of elements per step: alpha, d logvar_out)
 __device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g) {
   const nm_job_t* J = c.job;
   if (c.flags & NM_F_GRADS) asg(J->grads)[idx] = g;
   if (c.flags & NM_F_ADAM) {
     gf32 P_ = asg(J->params); gf32 M_ = asg(J->adam_m); gf32 V_ = asg(J->adam_v);
     float p = P_[idx], m = M_[idx], v = V_[idx];
-    m = m + (g - m) * (1.0f - J->beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * J->beta2 + (1.0f - J->beta2) * g * g;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-    float denom = sqrtf(v) * c.inv_bc2_sqrt + J->adam_eps;
-    p = p - c.step_size * (m / denom);
+    adam1(adam_consts(c), g, p, m, v);
     P_[idx] = p; M_[idx] = m; V_[idx] = v;
   }
 }
 
-// 4 gradient elements (one accumulator tile register group): loads first, then Adam, then stores
-__device__ __forceinline__ void apply_grad4(const Ctx& c, const int (&idx)[4], const bool (&ok)[4], const f32x4& g) {
+// 4 consecutive parameters (16-byte aligned): the unit of the coalesced sweep
+__device__ __forceinline__ void apply_grad_vec4(const Ctx& c, int64_t idx, f32x4 g) {
   const nm_job_t* J = c.job;
-  if (c.flags & NM_F_GRADS) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (ok[e]) asg(J->grads)[idx[e]] = g[e];
-  }
+  if (c.flags & NM_F_GRADS) *(GAS f32x4*)(asg(J->grads) + idx) = g;
   if (c.flags & NM_F_ADAM) {
-    float p[4], m[4], v[4];
-    gf32 P_ = asg(J->params);
-    gf32 M_ = asg(J->adam_m);
-    gf32 V_ = asg(J->adam_v);
+    GAS f32x4* P_ = (GAS f32x4*)(asg(J->params) + idx);
+    GAS f32x4* M_ = (GAS f32x4*)(asg(J->adam_m) + idx);
+    GAS f32x4* V_ = (GAS f32x4*)(asg(J->adam_v) + idx);
+    f32x4 p = *P_, m = *M_, v = *V_;
+    const AdamK a = adam_consts(c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { p[e] = P_[idx[e]]; m[e] = M_[idx[e]]; v[e] = V_[idx[e]]; }
-    const float b1 = J->beta1, b2 = J->beta2, ae = J->adam_eps;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      m[e] = m[e] + (g[e] - m[e]) * (1.0f - b1);
-      v[e] = v[e] * b2 + (1.0f - b2) * g[e] * g[e];
-      float denom = sqrtf(v[e]) * c.inv_bc2_sqrt + ae;
-      p[e] = p[e] - c.step_size * (m[e] / denom);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (ok[e]) { P_[idx[e]] = p[e]; M_[idx[e]] = m[e]; V_[idx[e]] = v[e]; }
+    for (int i = 0; i < 4; ++i) { float pp = p[i], mm = m[i], vv = v[i]; adam1(a, g[i], pp, mm, vv); p[i] = pp; m[i] = mm; v[i] = vv; }
+    *P_ = p; *M_ = m; *V_ = v;
   }
 }
 
 // ---- cooperative copies ----------------------------------------------------------------------
-// global bf16 [256][PW] (saved activation) -> LDS [256][LDP]
-__device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src) {
-  // 256 rows x 16 pieces of 16 B
-  for (int p = c.tid; p < ROWS * (PW / 8); p += WG) {
-    int row = p >> 4, seg = p & 15;
+// global bf16 [256][PW] (saved activation) <-> LDS [256][LDP]; only the first `width` columns move
+__device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src, int width) {
+  const int segs = width >> 3;                   // 16-byte pieces per row (width is a multiple of 32)
+  const float rs = 1.0f / (float)segs;
+  for (int p = c.tid; p < ROWS * segs; p += WG) {
+    int row = idiv(p, segs, rs), seg = p - row * segs;
     u32x4 v = *(const GAS u32x4*)(src + row * PW + seg * 8);
     *reinterpret_cast<u32x4*>(dst + row * LDP + seg * 8) = v;
+  }
+}
+__device__ __forceinline__ void store_act(const Ctx& c, gbf16 dst, const __bf16* src, int width) {
+  const int segs = width >> 3;
+  const float rs = 1.0f / (float)segs;
+  for (int p = c.tid; p < ROWS * segs; p += WG) {
+    int row = idiv(p, segs, rs), seg = p - row * segs;
+    u32x4 v = *reinterpret_cast<const u32x4*>(src + row * LDP + seg * 8);
+    *(GAS u32x4*)(dst + row * PW + seg * 8) = v;
   }
 }
 
@@ -319,6 +348,65 @@ __device__ __forceinline__ void xchunk_store(const Ctx& c, const XStage& s, __bf
   }
 }
 
+// [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer
+__device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_modality_t& md, gcf32 mu_j, gcf32 es, int Z,
+                                         int C, int Zs) {
+  const int Kd0 = Z + C, wz = wpad(Kd0);
+  const float rw = 1.0f / (float)wz;
+  gcbf16 xb = (gcbf16)asg(md.xb);
+#pragma unroll 4
+  for (int e = c.tid; e < ROWS * wz; e += WG) {
+    int r = idiv(e, wz, rw), k = e - r * wz;
+    float v;
+    if (k < Z) v = mu_j[r * Zs + k] + es[r * Zs + k];
+    else if (k < Kd0) v = (float)xb[(int64_t)(c.row0 + r) * md.Kx + md.D + (k - Z)];
+    else v = (k == Kd0) ? 1.0f : 0.0f;
+    dst[r * LDP + k] = (__bf16)v;
+  }
+}
+
+// ---- accumulator tile bookkeeping --------------------------------------------------------------
+// acc[t][rt]: feature tile ft = wn + 4 t, row tile rt; lane holds features ft*16 + 4g + i (i = 0..3)
+// of row wm*128 + rt*16 + c16.
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][8]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void bias_acc(const Ctx& c, f32x4 (&acc)[2][8], gcf32 b, int N, int f_base) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int f0 = f_base + (c.wn + 4 * t) * 16 + 4 * c.g;
+    f32x4 bv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float x = b[min(f0 + i, N - 1)]; bv[i] = (f0 + i < N) ? x : 0.f; }
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) acc[t][rt] = bv;
+  }
+}
+// activation epilogue: P[r][f] = act(acc) for f < N, 1 at f == N (ones column), 0 beyond
+__device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][8], int N, int ntn, bool act) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int ft = c.wn + 4 * t;
+    if (ft >= ntn) continue;
+    int f0 = ft * 16 + 4 * c.g;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+      int r = c.wm * 128 + rt * 16 + c.c16;
+      bf16x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[t][rt][i];
+        v = (f0 + i < N) ? lrelu(v, act) : (f0 + i == N ? 1.0f : 0.0f);
+        pk[i] = (__bf16)v;
+      }
+      *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
+    }
+  }
+}
+
 // ---- GEMM phase: forward layer, P -> P in place ---------------------------------------------
 // out[r][n] = act(sum_k P[r][k] W[n][k] + b[n]), n < N; column N := 1 (ones column feeding the
 // next layer's bias gradient), columns (N, wpad(N)) := 0.  Optionally saved to `save` (bf16
@@ -329,52 +417,30 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
   relaunder(c);
   const int ksteps = wpad(K) / 32;
   const int ntn = wpad(N) / 16;
-  f32x4 acc[8][2];
+  f32x4 acc[2][8];
+  bias_acc(c, acc, b, N, 0);
+  bf16x8 wcur[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int n = (c.wn + 4 * t) * 16 + c.c16;
-    float bv = (n < N) ? b[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
-  }
-  bf16x8 bcur[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) bcur[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, 8 * c.g);
+  for (int t = 0; t < 2; ++t) wcur[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, 8 * c.g);
   for (int ks = 0; ks < ksteps; ++ks) {
-    bf16x8 bnext[2];
+    bf16x8 wnext[2];
     if (ks + 1 < ksteps) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bnext[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (ks + 1) * 32 + 8 * c.g);
+      for (int t = 0; t < 2; ++t) wnext[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (ks + 1) * 32 + 8 * c.g);
     }
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+    for (int rt = 0; rt < 8; ++rt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        if ((c.wn + 4 * t) < ntn) acc[mt][t] = mfma(a, bcur[t], acc[mt][t]);
+        if ((c.wn + 4 * t) < ntn) acc[t][rt] = mfma(wcur[t], a, acc[t][rt]);
     }
-    if (ks + 1 < ksteps) { bcur[0] = bnext[0]; bcur[1] = bnext[1]; }
+    if (ks + 1 < ksteps) { wcur[0] = wnext[0]; wcur[1] = wnext[1]; }
   }
   __syncthreads();                       // every wave has finished reading P
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int nt = c.wn + 4 * t;
-    if (nt >= ntn) continue;
-    int n = nt * 16 + c.c16;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-        float v = acc[mt][t][i];
-        v = (n < N) ? lrelu(v, act) : (n == N ? 1.0f : 0.0f);
-        __bf16 hv = (__bf16)v;
-        c.P[r * LDP + n] = hv;
-        if (save) save[r * PW + n] = hv;
-      }
-    }
-  }
+  act_to_P(c, acc, N, ntn, act);
   __syncthreads();
+  if (save) store_act(c, save, c.P, wpad(N));
 }
 
 // ---- GEMM phase: first encoder layer, x streamed through Q in 64-column chunks ----------------
@@ -385,14 +451,8 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
   const int Kx = md.Kx;
   const int nch = (Kx + XCH - 1) / XCH;
   const int ntn = wpad(N) / 16;
-  f32x4 acc[8][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int n = (c.wn + 4 * t) * 16 + c.c16;
-    float bv = (n < N) ? b[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
-  }
+  f32x4 acc[2][8];
+  bias_acc(c, acc, b, N, 0);
   XStage st;
   xchunk_load(c, st, asg(md.xb), Kx, 0);
   for (int kc = 0; kc < nch; ++kc) {
@@ -403,39 +463,23 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
     for (int ks = 0; ks < 2; ++ks) {
       int kg = kc * XCH + ks * 32;
       if (kg < Kx) {
-        bf16x8 bf[2];
+        bf16x8 wf[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) bf[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, kg + 8 * c.g);
+        for (int t = 0; t < 2; ++t) wf[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, kg + 8 * c.g);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          bf16x8 a = lds_frag(c.Q, LDX, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+        for (int rt = 0; rt < 8; ++rt) {
+          bf16x8 a = lds_frag(c.Q, LDX, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            if ((c.wn + 4 * t) < ntn) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+            if ((c.wn + 4 * t) < ntn) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
         }
       }
     }
     __syncthreads();
   }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int nt = c.wn + 4 * t;
-    if (nt >= ntn) continue;
-    int n = nt * 16 + c.c16;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-        float v = acc[mt][t][i];
-        v = (n < N) ? lrelu(v, act) : (n == N ? 1.0f : 0.0f);
-        __bf16 hv = (__bf16)v;
-        c.P[r * LDP + n] = hv;
-        if (save) save[r * PW + n] = hv;
-      }
-    }
-  }
+  act_to_P(c, acc, N, ntn, act);
   __syncthreads();
+  if (save) store_act(c, save, c.P, wpad(N));
 }
 
 // ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
@@ -445,158 +489,89 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, g
   relaunder(c);
   const int ksteps = wpad(K) / 32;
   const int nzt = Zs / 16;
-  for (int nt = c.wn; nt < nzt; nt += 4) {
-    int n = nt * 16 + c.c16;
+  for (int ft = c.wn; ft < nzt; ft += 4) {
+    const int f0 = ft * 16 + 4 * c.g;
     f32x4 am[8], al[8];
-    float b0 = (n < Z) ? bmu[n] : 0.f, b1 = (n < Z) ? blv[n] : 0.f;
+    f32x4 b0, b1;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) { am[mt] = f32x4{b0, b0, b0, b0}; al[mt] = f32x4{b1, b1, b1, b1}; }
+    for (int i = 0; i < 4; ++i) {
+      float x0 = bmu[min(f0 + i, Z - 1)], x1 = blv[min(f0 + i, Z - 1)];
+      b0[i] = (f0 + i < Z) ? x0 : 0.f;
+      b1[i] = (f0 + i < Z) ? x1 : 0.f;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) { am[rt] = b0; al[rt] = b1; }
     for (int ks = 0; ks < ksteps; ++ks) {
-      bf16x8 fm = w_frag(Wmu, Z, K, n, ks * 32 + 8 * c.g);
-      bf16x8 fl = w_frag(Wlv, Z, K, n, ks * 32 + 8 * c.g);
+      bf16x8 fm = w_frag(Wmu, Z, K, ft * 16 + c.c16, ks * 32 + 8 * c.g);
+      bf16x8 fl = w_frag(Wlv, Z, K, ft * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
-        am[mt] = mfma(a, fm, am[mt]);
-        al[mt] = mfma(a, fl, al[mt]);
+      for (int rt = 0; rt < 8; ++rt) {
+        bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+        am[rt] = mfma(fm, a, am[rt]);
+        al[rt] = mfma(fl, a, al[rt]);
       }
     }
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-        mu_out[r * Zs + n] = (n < Z) ? am[mt][i] : 0.f;
-        lv_out[r * Zs + n] = (n < Z) ? al[mt][i] : 0.f;
-      }
+    for (int rt = 0; rt < 8; ++rt) {
+      int r = c.wm * 128 + rt * 16 + c.c16;
+      *(GAS f32x4*)(mu_out + r * Zs + f0) = am[rt];      // features >= Z are exactly 0 (masked weights, zero bias)
+      *(GAS f32x4*)(lv_out + r * Zs + f0) = al[rt];
     }
   }
   __syncthreads();
 }
 
-// ---- dgrad: acc[r][k] += sum_n P[r][n] W[n][k]  (contraction over P's columns) -----------------
-// k tiles {wn, wn+4} of wpad(K); nsteps = 32-wide steps over P's columns; n_base = index of P's
+// ---- dgrad: acc[k][r] += sum_n A[r][n] W[n][k]  (contraction over the columns of A) ------------
+// k tiles {wn, wn+4} of wpad(K); nsteps = 32-wide steps over A's columns; n_base = index of A's
 // column 0 in W's row space.
-__device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[8][2], const __bf16* A, gcf32 W, int N, int K,
+__device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][8], const __bf16* A, gcf32 W, int N, int K,
                                           int nsteps, int n_base) {
   Ctx c = cc;
   relaunder(c);
   const int ntk = wpad(K) / 16;
   for (int s = 0; s < nsteps; ++s) {
-    bf16x8 bf[2];
+    bf16x8 wf[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-      bf[t] = w_frag_t(W, N, K, n_base + s * 32 + 8 * c.g, (c.wn + 4 * t) * 16 + c.c16);
+      wf[t] = w_frag_t(W, N, K, n_base + s * 32 + 8 * c.g, (c.wn + 4 * t) * 16 + c.c16);
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      bf16x8 a = lds_frag(A, LDP, c.wm * 128 + mt * 16 + c.c16, s * 32 + 8 * c.g);
+    for (int rt = 0; rt < 8; ++rt) {
+      bf16x8 a = lds_frag(A, LDP, c.wm * 128 + rt * 16 + c.c16, s * 32 + 8 * c.g);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        if ((c.wn + 4 * t) < ntk) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+        if ((c.wn + 4 * t) < ntk) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
     }
   }
 }
 
 // dgrad through the two encoder heads: P columns [0,Zs) = d mu, [Zs,2Zs) = d logvar
-__device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[8][2], gcf32 Wmu, gcf32 Wlv, int Z, int K,
+__device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[2][8], gcf32 Wmu, gcf32 Wlv, int Z, int K,
                                             int Zs) {
   Ctx c = cc;
   relaunder(c);
   const int ntk = wpad(K) / 16;
   const int nsteps = rup(2 * Zs, 32) / 32;
   for (int s = 0; s < nsteps; ++s) {
-    bf16x8 bf[2];
+    bf16x8 wf[2];
     int nn0 = s * 32 + 8 * c.g;              // 8-aligned, Zs is a multiple of 16: never straddles
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       int k = (c.wn + 4 * t) * 16 + c.c16;
-      bf[t] = (nn0 < Zs) ? w_frag_t(Wmu, Z, K, nn0, k) : w_frag_t(Wlv, Z, K, nn0 - Zs, k);
+      wf[t] = (nn0 < Zs) ? w_frag_t(Wmu, Z, K, nn0, k) : w_frag_t(Wlv, Z, K, nn0 - Zs, k);
     }
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, s * 32 + 8 * c.g);
+    for (int rt = 0; rt < 8; ++rt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, s * 32 + 8 * c.g);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        if ((c.wn + 4 * t) < ntk) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+        if ((c.wn + 4 * t) < ntk) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
     }
   }
 }
 
-// ---- wgrad + Adam: dW[n][k] = sum_r A[r][a_col0 + n] * B[r][k] -------------------------------
-// n in [0,N) (ntn tiles), B columns kk in [0, nkt*16) map to global k = k_base + kk; k < K is a
-// weight W[n][k], k == K the bias b[n] (ones column), beyond: nothing.  Work unit = one n-tile x
-// up to four k-tiles, dealt round-robin to the 8 waves.
-template <bool SCALAR_TR>
-__device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb, int N, int K,
-                           int k_base, int nkt, int64_t w_off, int64_t b_off) {
-  Ctx c = cc;
-  relaunder(c);
-  const int ntn = (N + 15) / 16;
-  const int kgroups = (nkt + 3) / 4;
-  const int units = ntn * kgroups;
-  for (int u = c.wave; u < units; u += NWAVES) {
-    int nt = u / kgroups, kg = u % kgroups;
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (SCALAR_TR) {
-      for (int rs = 0; rs < ROWS / 32; ++rs) {
-        bf16x8 a = lds_frag_tr_scalar(A, lda, rs * 32, a_col0 + nt * 16, c.lane);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          int kt = kg * 4 + t;
-          if (kt < nkt) {
-            bf16x8 b = lds_frag_tr_scalar(B, ldb, rs * 32, kt * 16, c.lane);
-            acc[t] = mfma(a, b, acc[t]);
-          }
-        }
-      }
-    } else {
-      unsigned aa = tr_addr(A, lda, 0, a_col0 + nt * 16, c.lane);
-      unsigned ba = tr_addr(B, ldb, 0, kg * 64, c.lane);
-      const unsigned a_step = 32u * lda * 2u, b_step = 32u * ldb * 2u;
-      const unsigned a4 = 4u * lda * 2u, b4 = 4u * ldb * 2u;
-      for (int rs = 0; rs < ROWS / 32; ++rs) {
-        bf16x4 a0, a1, b0[4], b1[4];
-        unsigned aa1 = aa + a4, ba1 = ba + b4;
-        NM_TR_READ(a0, aa, 0);
-        NM_TR_READ(a1, aa1, 0);
-        NM_TR_READ(b0[0], ba, 0);  NM_TR_READ(b1[0], ba1, 0);
-        NM_TR_READ(b0[1], ba, 32); NM_TR_READ(b1[1], ba1, 32);
-        NM_TR_READ(b0[2], ba, 64); NM_TR_READ(b1[2], ba1, 64);
-        NM_TR_READ(b0[3], ba, 96); NM_TR_READ(b1[3], ba1, 96);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]),
-                       "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
-        bf16x8 a = join4(a0, a1);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (kg * 4 + t < nkt) acc[t] = mfma(a, join4(b0[t], b1[t]), acc[t]);
-        aa += a_step; ba += b_step;
-      }
-    }
-    // epilogue, one 16x16 tile at a time: its 4 elements' p, m, v loads are issued together
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      int kt = kg * 4 + t;
-      int k = k_base + kt * 16 + c.c16;
-      int idx[4];
-      bool ok[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int n = nt * 16 + 4 * c.g + i;
-        bool v = (kt < nkt) && (n < N) && (k <= K);
-        int64_t ix = (k < K) ? w_off + (int64_t)n * K + k : b_off + n;
-        ok[i] = v;
-        idx[i] = v ? (int)ix : 0;
-      }
-      apply_grad4(c, idx, ok, acc[t]);
-    }
-  }
-}
-
-// P[r][k] = acc[r][k] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
-__device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[8][2], const __bf16* src, int K, bool act) {
+// P[r][k] = acc[k][r] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
+__device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2][8], const __bf16* src, int K,
+                                             bool act) {
   Ctx c = cc;
   relaunder(c);
   const int ntk = wpad(K) / 16;
@@ -604,25 +579,127 @@ __device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[8
   for (int t = 0; t < 2; ++t) {
     int kt = c.wn + 4 * t;
     if (kt >= ntk) continue;
-    int k = kt * 16 + c.c16;
+    int k0 = kt * 16 + 4 * c.g;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int rt = 0; rt < 8; ++rt) {
+      int r = c.wm * 128 + rt * 16 + c.c16;
+      bf16x4 a = *reinterpret_cast<const bf16x4*>(src + r * LDP + k0);
+      bf16x4 pk;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-        float a = (float)src[r * LDP + k];
-        float d = acc[mt][t][i];
-        if (act && !(a > 0.f)) d *= SLOPE;
-        if (k >= K) d = 0.f;
-        c.P[r * LDP + k] = (__bf16)d;
+        float d = acc[t][rt][i];
+        if (act && !((float)a[i] > 0.f)) d *= SLOPE;
+        if (k0 + i >= K) d = 0.f;
+        pk[i] = (__bf16)d;
       }
+      *reinterpret_cast<bf16x4*>(c.P + r * LDP + k0) = pk;
     }
   }
 }
 
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[8][2]) {
+// ---- wgrad + Adam ------------------------------------------------------------------------------
+// dW[n][k] = sum_r A[r][a_col0 + n] * B[r][kk], n in [0,N), B columns kk in [0, ncols) map to the
+// weight column k = k_base + kk; k < K is W[n][k], k == K the bias b[n] (ones column), beyond:
+// nothing.  The output is produced in slabs of SR rows x SC columns (32 x 128 or 64 x 64): the 8
+// waves write their accumulator tiles (4 consecutive k per lane, 16 bytes) into the LDS slab S,
+// then all 512 threads sweep the slab's parameter range with 16-byte p/m/v accesses.
+template <bool SCALAR_TR>
+__device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
+                                           int N, int K, int k_base, int ncols, int64_t w_off, int64_t b_off) {
+  Ctx c = cc;
+  relaunder(c);
+  const bool wide = ncols > 64;                 // slab shape
+  const int SR = wide ? 32 : 64, SP = (wide ? 128 : 64) + 4;      // slab rows, slab pitch (floats)
+  const int nkt = (ncols + 15) / 16;            // k tiles in this pass
+  const int kpairs = (nkt + 1) / 2;
+  const int ncv = max(0, min(ncols, K - k_base));               // weight columns in this pass
+  const bool has_bias = (K >= k_base) && (K < k_base + ncols);
+  const bool contig = (k_base == 0) && (ncv == K);              // slab rows are whole weight rows
+  for (int n0 = 0; n0 < N; n0 += SR) {
+    const int nr = min(SR, N - n0);
+    const int nts = (nr + 15) / 16;
+    // ---- tiles -> slab ----
+    for (int u = c.wave; u < nts * kpairs; u += NWAVES) {
+      const int nt = u / kpairs, kp = u - nt * kpairs;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int ncol = a_col0 + n0 + nt * 16;
+      if (SCALAR_TR) {
+        for (int rs = 0; rs < ROWS / 32; ++rs) {
+          bf16x8 bn = lds_frag_tr_scalar(A, lda, rs * 32, ncol, c.lane);
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          for (int t = 0; t < 2; ++t) {
+            bf16x8 ak = lds_frag_tr_scalar(B, ldb, rs * 32, (kp * 2 + t) * 16, c.lane);
+            acc[t] = mfma(ak, bn, acc[t]);
+          }
+        }
+      } else {
+        unsigned na = tr_addr(A, lda, 0, ncol, c.lane);
+        unsigned ka = tr_addr(B, ldb, 0, kp * 32, c.lane);
+        const unsigned n_step = 32u * lda * 2u, k_step = 32u * ldb * 2u;
+        const unsigned n4 = 4u * lda * 2u, k4 = 4u * ldb * 2u;
+#pragma unroll 2
+        for (int rs = 0; rs < ROWS / 32; ++rs) {
+          bf16x4 n0v, n1v, k0v[2], k1v[2];
+          unsigned na1 = na + n4, ka1 = ka + k4;
+          NM_TR_READ(n0v, na, 0);
+          NM_TR_READ(n1v, na1, 0);
+          NM_TR_READ(k0v[0], ka, 0);  NM_TR_READ(k1v[0], ka1, 0);
+          NM_TR_READ(k0v[1], ka, 32); NM_TR_READ(k1v[1], ka1, 32);
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(n0v), "+v"(n1v), "+v"(k0v[0]), "+v"(k1v[0]), "+v"(k0v[1]), "+v"(k1v[1]));
+          bf16x8 bn = join4(n0v, n1v);
+          acc[0] = mfma(join4(k0v[0], k1v[0]), bn, acc[0]);
+          acc[1] = mfma(join4(k0v[1], k1v[1]), bn, acc[1]);
+          na += n_step; ka += k_step;
+        }
+      }
+      // lane holds dW[n = nt*16 + c16][kk = (kp*2 + t)*16 + 4g .. +3]
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (kp * 2 + t < nkt)
+          *reinterpret_cast<f32x4*>(c.stage + (nt * 16 + c.c16) * SP + (kp * 2 + t) * 16 + 4 * c.g) = acc[t];
+    }
+    __syncthreads();
+    // ---- coalesced sweep over the slab's parameters ----
+    if (contig) {
+      const int total = nr * K;
+      const int64_t base = w_off + (int64_t)n0 * K;              // 16-byte aligned: w_off % 4 == 0, n0 % 32 == 0
+      const float rk = 1.0f / (float)K;
+      for (int q = c.tid; q < (total + 3) / 4; q += WG) {
+        int e = 4 * q;
+        int n = idiv(e, K, rk), k = e - n * K;
+        f32x4 g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          g[i] = c.stage[min(n, nr - 1) * SP + k];
+          ++k;
+          if (k == K) { k = 0; ++n; }
+        }
+        if (e + 4 <= total) apply_grad_vec4(c, base + e, g);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (e + i < total) apply_grad(c, base + e + i, g[i]);
+        }
+      }
+    } else if (ncv > 0 && (K & 3) == 0 && (ncv & 3) == 0) {
+      const int gpr = ncv >> 2;                                   // 16-byte groups per row
+      const float rg = 1.0f / (float)gpr;
+      for (int q = c.tid; q < nr * gpr; q += WG) {
+        int n = idiv(q, gpr, rg), k4 = q - n * gpr;
+        f32x4 g = *reinterpret_cast<const f32x4*>(c.stage + n * SP + 4 * k4);
+        apply_grad_vec4(c, w_off + (int64_t)(n0 + n) * K + k_base + 4 * k4, g);
+      }
+    } else if (ncv > 0) {
+      const float rc = 1.0f / (float)ncv;
+      for (int q = c.tid; q < nr * ncv; q += WG) {
+        int n = idiv(q, ncv, rc), k = q - n * ncv;
+        apply_grad(c, w_off + (int64_t)(n0 + n) * K + k_base + k, c.stage[n * SP + k]);
+      }
+    }
+    if (has_bias && c.tid < nr) apply_grad(c, b_off + n0 + c.tid, c.stage[c.tid * SP + (K - k_base)]);
+    __syncthreads();
+  }
 }
 
 // ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
@@ -730,6 +807,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const bool exportf = (c.flags & NM_F_EXPORT) != 0;
   const WsLayout wl = ws_layout(M, L, Z);
   const int Zs = wl.Zs;
+  const float rZ = 1.0f / (float)Z;
   gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m);
   gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m);
   gf32 ws_mu_j = (gf32)(c.ws + wl.mu_j);
@@ -760,16 +838,18 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // ================= fusion + reparameterisation + KL =================
   float al[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
   if (J->combine == NM_COMBINE_GPOE && !(M == 1 && J->single_bypass)) softmax_alpha(J, al);
-  auto load_lat = [&](Lat& L, int r, int z) {
+  auto load_lat = [&](Lat& Lt, int r, int z) {
 #pragma unroll
     for (int m = 0; m < NM_MAX_MOD; ++m) {
-      L.mu[m] = (m < M) ? ws_mu_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
-      L.lv[m] = (m < M) ? ws_lv_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
+      Lt.mu[m] = (m < M) ? ws_mu_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
+      Lt.lv[m] = (m < M) ? ws_lv_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
     }
   };
   float kl_part = 0.f;
+  relaunder(c);
+#pragma unroll 2
   for (int e = c.tid; e < ROWS * Z; e += WG) {
-    int r = e / Z, z = e - r * Z;
+    int r = idiv(e, Z, rZ), z = e - r * Z;
     Lat Lt;
     load_lat(Lt, r, z);
     Fuse f = fuse_fwd(J, Lt, al);
@@ -800,17 +880,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int D = md.D;
-    // --- build zc = [z | c | 1 | 0] in P ---
     const int Kd0 = Z + C;
-    for (int e = c.tid; e < ROWS * wpad(Kd0); e += WG) {
-      int wz = wpad(Kd0);
-      int r = e / wz, k = e - r * wz;
-      float v;
-      if (k < Z) v = ws_mu_j[r * Zs + k] + ws_es[r * Zs + k];
-      else if (k < Kd0) v = (float)((gcbf16)asg(md.xb))[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
-      else v = (k == Kd0) ? 1.0f : 0.0f;
-      c.P[r * LDP + k] = (__bf16)v;
-    }
+    build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
     __syncthreads();
     prof(c, PH_DEC_ZC);
     // --- hidden decoder layers ---
@@ -826,7 +897,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     gcf32 Wo = prm + md.out_w;
     gcf32 bo = prm + md.out_b;
     gcf32 lvo = prm + md.logvar_out;
-    f32x4 accg[8][2];
+    gcf32 xf = asg(md.x_f32);
+    const int xp = md.x_pitch;
+    f32x4 accg[2][8];
     zero_acc(accg);
     float nll_part = 0.f;
     if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
@@ -837,73 +910,77 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const int valid = min(PW, D - d0);
       if (c.tid < PW) c.colacc[c.tid] = 0.f;
       __syncthreads();
-      // x_hat chunk
+      // x_hat chunk: acc[d][r]
       {
-        f32x4 acc[8][2];
+        f32x4 acc[2][8];
         const int ksteps = wpad(Hl) / 32;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          int d = d0 + (c.wn + 4 * t) * 16 + c.c16;
-          float bv = (d < D) ? bo[d] : 0.f;
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt) acc[mt][t] = f32x4{bv, bv, bv, bv};
-        }
+        bias_acc(c, acc, bo, D, d0);
         for (int ks = 0; ks < ksteps; ++ks) {
-          bf16x8 bf[2];
+          bf16x8 wf[2];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) bf[t] = w_frag(Wo, D, Hl, d0 + (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+          for (int t = 0; t < 2; ++t) wf[t] = w_frag(Wo, D, Hl, d0 + (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {
-            bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+          for (int rt = 0; rt < 8; ++rt) {
+            bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+            for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
           }
         }
-        // epilogue: residual, NLL, d logvar_out, delta chunk -> Q
+        // epilogue: residual, NLL, d logvar_out, delta chunk -> Q.  Lane: 4 consecutive ROI of one row.
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          int dl = (c.wn + 4 * t) * 16 + c.c16;     // column inside the chunk
-          int d = d0 + dl;
-          bool dv = d < D;
-          float s = dv ? lvo[d] : 0.f;
-          float inv = expf(-s);
-          float colsum = 0.f;
-          // all 32 inputs of this column first (rows are always inside the zero-padded table)
-          const int dcl = min(d, D - 1);
+          const int dl0 = (c.wn + 4 * t) * 16 + 4 * c.g;       // first of the lane's 4 columns inside the chunk
+          const int dg0 = d0 + dl0;
+          float sv[4], inv[4], colsum[4];
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {
-            // the 4 inputs of this row tile first (rows are always inside the zero-padded table)
-            float xin[4];
+          for (int i = 0; i < 4; ++i) {
+            sv[i] = lvo[min(dg0 + i, D - 1)];
+            inv[i] = expf(-sv[i]);
+            colsum[i] = 0.f;
+          }
+          // the 8 rows' inputs first: 8 x 16 bytes in flight (rows are always inside the zero-padded table)
+          f32x4 xin[8];
+          const int dcl = min(dg0, xp - 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              xin[i] = asg(md.x_f32)[(int64_t)(c.row0 + c.wm * 128 + mt * 16 + 4 * c.g + i) * D + dcl];
+          for (int rt = 0; rt < 8; ++rt)
+            xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * 128 + rt * 16 + c.c16) * xp + dcl);
+#pragma unroll
+          for (int rt = 0; rt < 8; ++rt) {
+            const int r = c.wm * 128 + rt * 16 + c.c16;
+            const bool rv = r < c.nrows;
+            bf16x4 pk;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-              bool ok = dv && r < c.nrows;
+              const bool ok = rv && (dg0 + i < D);
+              float xh = acc[t][rt][i];
+              float diff = xh - xin[rt][i];
+              float q = diff * diff * inv[i];
               float delta = 0.f;
               if (ok) {
-                int64_t gi = (int64_t)(c.row0 + r) * D + d;
-                float x = xin[i];
-                float xh = acc[mt][t][i];
-                float diff = xh - x;
-                float q = diff * diff * inv;
-                nll_part += 0.5f * q + 0.5f * s + LOG_SQRT_2PI;
-                colsum += 0.5f - 0.5f * q;
-                delta = J->ll_weight * diff * inv * c.inv_b;
+                nll_part += 0.5f * q + 0.5f * sv[i] + LOG_SQRT_2PI;
+                colsum[i] += 0.5f - 0.5f * q;
+                delta = J->ll_weight * diff * inv[i] * c.inv_b;
                 if (exportf) {
+                  int64_t gi = (int64_t)(c.row0 + r) * D + dg0 + i;
                   if (md.out_loc) asg(md.out_loc)[gi] = xh;
                   if (md.out_sqerr) asg(md.out_sqerr)[gi] = diff * diff;
                   if (md.out_rowdev) atomicAdd(&c.rowacc[r], diff * diff);
                 }
               }
-              if (bwd) c.Q[r * LDP + dl] = (__bf16)delta;
+              pk[i] = (__bf16)delta;
             }
+            if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
           }
           if (bwd) {
-            colsum += __shfl_xor(colsum, 16, 64);
-            colsum += __shfl_xor(colsum, 32, 64);
-            if (c.g == 0 && dv) atomicAdd(&c.colacc[dl], colsum);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float s = colsum[i];
+              s += __shfl_xor(s, 1, 64);
+              s += __shfl_xor(s, 2, 64);
+              s += __shfl_xor(s, 4, 64);
+              s += __shfl_xor(s, 8, 64);
+              if (c.c16 == 0 && dg0 + i < D) atomicAdd(&c.colacc[dl0 + i], s);
+            }
           }
         }
       }
@@ -912,15 +989,14 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       prof(c, PH_OUT_GEMM);
       // d logvar_out for this chunk
       if (c.tid < valid) apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b);
-      // dgrad into the last hidden activation: accg[r][k] += sum_d Q[r][d] Wo[d0 + d][k]
       prof(c, PH_OUT_DLV);
+      // dgrad into the last hidden activation: accg[k][r] += sum_d Q[r][d] Wo[d0 + d][k]
       dgrad_acc(c, accg, c.Q, Wo, D, Hl, rup(valid, 32) / 32, d0);
       __syncthreads();                              // all reads of the old Wo are done
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
-      wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, (Hl + 1 + 15) / 16,
+      wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, rup(Hl + 1, 16),
                             md.out_w + (int64_t)d0 * Hl, md.out_b + d0);
-      __syncthreads();
       prof(c, PH_OUT_WGRAD);
     }
     float nll = block_sum(c, nll_part);
@@ -945,28 +1021,16 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
       // Q <- input activation of decoder layer d
-      if (d == 0) {
-        for (int e = c.tid; e < ROWS * wpad(Kd0); e += WG) {
-          int wz = wpad(Kd0);
-          int r = e / wz, k = e - r * wz;
-          float v;
-          if (k < Z) v = ws_mu_j[r * Zs + k] + ws_es[r * Zs + k];
-          else if (k < Kd0) v = (float)((gcbf16)asg(md.xb))[(int64_t)(c.row0 + r) * md.Kx + D + (k - Z)];
-          else v = (k == Kd0) ? 1.0f : 0.0f;
-          c.Q[r * LDP + k] = (__bf16)v;
-        }
-      } else {
-        load_act(c, c.Q, ws_dec + (int64_t)(d - 1) * ROWS * PW);
-      }
+      if (d == 0) build_zc(c, c.Q, md, ws_mu_j, ws_es, Z, C, Zs);
+      else load_act(c, c.Q, ws_dec + (int64_t)(d - 1) * ROWS * PW, wpad(Kin));
       __syncthreads();
       prof(c, PH_DEC_LOAD);
-      f32x4 acc[8][2];
+      f32x4 acc[2][8];
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.dec_w[d], Nout, Kin, wpad(Nout) / 32, 0);
       __syncthreads();                              // old weights fully read
       prof(c, PH_DEC_DGRAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, (Kin + 1 + 15) / 16, md.dec_w[d], md.dec_b[d]);
-      __syncthreads();
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.dec_w[d], md.dec_b[d]);
       prof(c, PH_DEC_WGRAD);
       if (d > 0) {
         finish_delta(c, acc, c.Q, Kin, nl);
@@ -977,15 +1041,14 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         for (int t = 0; t < 2; ++t) {
           int kt = c.wn + 4 * t;
           if (kt >= ntk) continue;
-          int k = kt * 16 + c.c16;
-          if (k < Z) {
+          int k0 = kt * 16 + 4 * c.g;
+          if (k0 < Z) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-                ws_dz[r * Zs + k] += acc[mt][t][i];
-              }
+            for (int rt = 0; rt < 8; ++rt) {
+              int r = c.wm * 128 + rt * 16 + c.c16;
+              GAS f32x4* p = (GAS f32x4*)(ws_dz + r * Zs + k0);    // columns >= Z of the row are never read
+              *p = *p + acc[t][rt];
+            }
           }
         }
       }
@@ -995,13 +1058,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
 
   // ================= loss log =================
-  {
-    if (c.tid == 0 && J->loss_log) {
-      gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
-      row[NM_LOSS_KL] = J->kl_weight * kl;
-      row[NM_LOSS_LL] = ll_sum;
-      row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
-    }
+  if (c.tid == 0 && J->loss_log) {
+    gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
+    row[NM_LOSS_KL] = J->kl_weight * kl;
+    row[NM_LOSS_LL] = ll_sum;
+    row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
   }
   if (!bwd) return;
   prof(c, PH_ALPHA);
@@ -1010,9 +1071,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const bool fused = !(M == 1 && J->single_bypass);
   const float klw = J->kl_weight * c.inv_b;
   if (fused && J->combine == NM_COMBINE_GPOE) {
+    relaunder(c);
     float dal[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
     for (int e = c.tid; e < c.nrows * Z; e += WG) {
-      int r = e / Z, z = e - r * Z;
+      int r = idiv(e, Z, rZ), z = e - r * Z;
       Lat Lt;
       load_lat(Lt, r, z);
       float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
@@ -1042,9 +1104,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const nm_modality_t& md = J->mod[m];
     const int Hh = J->H[L - 1];
     const int whp = rup(2 * Zs, 32);
+    const float rwh = 1.0f / (float)whp;
     // P <- [d mu_m | d logvar_m], Q <- last hidden activation
+#pragma unroll 2
     for (int e = c.tid; e < ROWS * whp; e += WG) {
-      int r = e / whp, k = e - r * whp;
+      int r = idiv(e, whp, rwh), k = e - r * whp;
       int z = (k < Zs) ? k : k - Zs;
       float v = 0.f;
       if (z < Z && k < 2 * Zs && r < c.nrows) {
@@ -1058,32 +1122,30 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       }
       c.P[r * LDP + k] = (__bf16)v;
     }
-    load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW);
+    load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW, wpad(Hh));
     __syncthreads();
     prof(c, PH_ENCB_PREP);
-    f32x4 acc[8][2];
+    f32x4 acc[2][8];
     zero_acc(acc);
     dgrad_heads(c, acc, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
     __syncthreads();
     prof(c, PH_ENCB_HEADS_DGRAD);
-    wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, (Hh + 1 + 15) / 16, md.mu_w, md.mu_b);
-    wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, (Hh + 1 + 15) / 16, md.lv_w, md.lv_b);
-    __syncthreads();
+    wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.mu_w, md.mu_b);
+    wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.lv_w, md.lv_b);
     prof(c, PH_ENCB_HEADS_WGRAD);
     finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
     __syncthreads();
     prof(c, PH_ENCB_DELTA);
     for (int e = L - 1; e >= 1; --e) {
       int Kin = J->H[e - 1], Nout = J->H[e];
-      load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW);
+      load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW, wpad(Kin));
       __syncthreads();
       prof(c, PH_ENCB_LOAD);
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.enc_w[e], Nout, Kin, wpad(Nout) / 32, 0);
       __syncthreads();
       prof(c, PH_ENCB_DGRAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, (Kin + 1 + 15) / 16, md.enc_w[e], md.enc_b[e]);
-      __syncthreads();
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.enc_w[e], md.enc_b[e]);
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
       __syncthreads();
@@ -1100,8 +1162,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         __syncthreads();
         if (kc + 1 < nch) xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
         int cols = min(XCH, Kx - kc * XCH);
-        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDX, N0, K0, kc * XCH, cols / 16, md.enc_w[0], md.enc_b[0]);
-        __syncthreads();
+        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDX, N0, K0, kc * XCH, cols, md.enc_w[0], md.enc_b[0]);
       }
       prof(c, PH_ENCB_L0_WGRAD);
     }
@@ -1109,6 +1170,17 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 }
 
 // ----------------------------------------------------------------------------------------------
+constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (STAGE_FLOATS + 64 + 128 + 256) * 4;
+
+__device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
+  c.P = reinterpret_cast<__bf16*>(smem);
+  c.Q = c.P + ROWS * LDP;
+  c.stage = reinterpret_cast<float*>(c.Q + ROWS * LDP);
+  c.red = c.stage + STAGE_FLOATS;
+  c.colacc = c.red + 64;
+  c.rowacc = c.colacc + 128;
+}
+
 template <bool SCALAR_TR>
 __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict__ jobs, int step0, int steps_per_tile,
                                                      int flags) {
@@ -1116,16 +1188,13 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   const nm_job_t* J = jobs + blockIdx.x;
   Ctx c;
   c.job = J;
-  c.P = reinterpret_cast<__bf16*>(smem);
-  c.Q = c.P + ROWS * LDP;
-  c.red = reinterpret_cast<float*>(c.Q + ROWS * LDP);
-  c.colacc = c.red + 64;
-  c.rowacc = c.colacc + 128;
+  carve_lds(c, smem);
   relaunder(c);
   c.flags = flags;
+  c.t_last = 0;
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   // zero LDS once: padded columns are multiplied by zero weights and must stay finite
-  for (int i = c.tid; i < 2 * ROWS * LDP / 2; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
   const int s_begin = step0 + blockIdx.y * steps_per_tile;
@@ -1138,7 +1207,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     const double tt = (double)(J->adam_off + (int64_t)s + 1);
     c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
-    if (flags & 16) c.t_last = clock64();
+    if (flags & NM_F_PROFILE) c.t_last = clock64();
     relaunder(c);
     run_step<SCALAR_TR>(c, s);
     __syncthreads();
@@ -1151,18 +1220,16 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
                                  float inv_bc2_sqrt) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const AdamK a{b1, b2, eps, step_size, inv_bc2_sqrt};
   for (; i < n; i += stride) {
-    float gg = g[i], mm = m[i], vv = v[i];
-    mm = mm + (gg - mm) * (1.0f - b1);
-    vv = vv * b2 + (1.0f - b2) * gg * gg;
-    float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mm / denom);
-    m[i] = mm; v[i] = vv;
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam1(a, g[i], pp, mm, vv);
+    p[i] = pp; m[i] = mm; v[i] = vv;
   }
 }
 
 __global__ void pack_table_kernel(const float* __restrict__ x, const float* __restrict__ cc, int n_rows, int rows_alloc,
-                                  int D, int C, int Kx, uint16_t* __restrict__ xb, float* __restrict__ xf) {
+                                  int D, int C, int Kx, uint16_t* __restrict__ xb, float* __restrict__ xf, int xp) {
   int64_t total = (int64_t)rows_alloc * Kx;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int r = (int)(i / Kx), k = (int)(i - (int64_t)r * Kx);
@@ -1174,56 +1241,52 @@ __global__ void pack_table_kernel(const float* __restrict__ x, const float* __re
     }
     __bf16 h = (__bf16)v;
     xb[i] = __builtin_bit_cast(uint16_t, h);
-    if (xf && k < D) xf[(int64_t)r * D + k] = (r < n_rows) ? x[(int64_t)r * D + k] : 0.f;
+    if (xf && k < xp) xf[(int64_t)r * xp + k] = (r < n_rows && k < D) ? x[(int64_t)r * D + k] : 0.f;
   }
 }
 
-// Unit-test kernel: one workgroup, C[M][N] = A[M][K] B[N][K]^T via the production fragment loaders.
-//   mode 0  forward form : A (M=256 rows, K<=128) staged row-major in P, B fp32 [N][K]
-//   mode 1  dgrad form   : C[r][k] = sum_n A[r][n] B[n][k]  (A [256][N'], B fp32 [N'][K'])
-//   mode 2/3 wgrad form  : C[n][k] = sum_r A[r][n] B[r][k]  (tr-read / scalar loaders)
+// Unit-test kernel: one workgroup, through the production fragment loaders and lane maps.
+//   mode 0  forward form : C[r][n] = sum_k A[r][k] B[n][k]   (A [256][K] via P, B fp32 [N][K])
+//   mode 1  dgrad form   : C[r][k] = sum_n A[r][n] B[n][k]   (A [256][N] via P, B fp32 [N][K])
+//   mode 2/3 wgrad form  : C[n][k] = sum_r A[r][n] B[r][k]   (ds_read_b64_tr_b16 / scalar loaders)
 __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A, const float* B, float* Cout, int M,
                                                        int N, int K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Ctx c;
-  c.P = reinterpret_cast<__bf16*>(smem);
-  c.Q = c.P + ROWS * LDP;
-  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.wm = c.wave >> 2; c.wn = c.wave & 3;
-  c.g = c.lane >> 4; c.c16 = c.lane & 15;
-  for (int i = c.tid; i < 2 * ROWS * LDP / 2; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  carve_lds(c, smem);
+  relaunder(c);
+  for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   if (mode == 0 || mode == 1) {
-    // A is [256][KA] with KA = (mode == 0 ? K : N)
     int KA = (mode == 0) ? K : N;
     for (int e = c.tid; e < ROWS * KA; e += WG) { int r = e / KA, k = e - r * KA; c.P[r * LDP + k] = (__bf16)A[e]; }
     __syncthreads();
-    f32x4 acc[8][2];
+    f32x4 acc[2][8];
     zero_acc(acc);
     int ncols = (mode == 0) ? N : K;
     if (mode == 0) {
       for (int ks = 0; ks < rup(K, 32) / 32; ++ks) {
-        bf16x8 bf[2];
-        for (int t = 0; t < 2; ++t) bf[t] = w_frag(asg(B), N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+        bf16x8 wf[2];
+        for (int t = 0; t < 2; ++t) wf[t] = w_frag(asg(B), N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + mt * 16 + c.c16, ks * 32 + 8 * c.g);
+        for (int rt = 0; rt < 8; ++rt) {
+          bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[mt][t] = mfma(a, bf[t], acc[mt][t]);
+          for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
         }
       }
     } else {
-      // emulate wpad semantics: dgrad_acc masks k tiles with wpad(K)
       dgrad_acc(c, acc, c.P, asg(B), N, K, rup(N, 32) / 32, 0);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      int n = (c.wn + 4 * t) * 16 + c.c16;
+      int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
+      for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int r = c.wm * 128 + mt * 16 + 4 * c.g + i;
-          if (n < ncols) Cout[(int64_t)r * ncols + n] = acc[mt][t][i];
+          int r = c.wm * 128 + rt * 16 + c.c16;
+          if (f0 + i < ncols) Cout[(int64_t)r * ncols + f0 + i] = acc[t][rt][i];
         }
     }
   } else {
@@ -1231,41 +1294,37 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
     for (int e = c.tid; e < ROWS * N; e += WG) { int r = e / N, k = e - r * N; c.P[r * LDP + k] = (__bf16)A[e]; }
     for (int e = c.tid; e < ROWS * K; e += WG) { int r = e / K, k = e - r * K; c.Q[r * LDP + k] = (__bf16)B[e]; }
     __syncthreads();
-    const int ntn = (N + 15) / 16, nkt = (K + 15) / 16, kgroups = (nkt + 3) / 4;
-    for (int u = c.wave; u < ntn * kgroups; u += NWAVES) {
-      int nt = u / kgroups, kg = u % kgroups;
-      f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    const int ntn = (N + 15) / 16, nkt = (K + 15) / 16, kpairs = (nkt + 1) / 2;
+    for (int u = c.wave; u < ntn * kpairs; u += NWAVES) {
+      int nt = u / kpairs, kp = u % kpairs;
+      f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
       for (int rs = 0; rs < ROWS / 32; ++rs) {
-        bf16x8 a;
-        bf16x8 b[4];
+        bf16x8 bn, ak[2];
         if (mode == 3) {
-          a = lds_frag_tr_scalar(c.P, LDP, rs * 32, nt * 16, c.lane);
-          for (int t = 0; t < 4; ++t) b[t] = lds_frag_tr_scalar(c.Q, LDP, rs * 32, (kg * 4 + t) * 16, c.lane);
+          bn = lds_frag_tr_scalar(c.P, LDP, rs * 32, nt * 16, c.lane);
+          for (int t = 0; t < 2; ++t) ak[t] = lds_frag_tr_scalar(c.Q, LDP, rs * 32, (kp * 2 + t) * 16, c.lane);
         } else {
-          unsigned aa = tr_addr(c.P, LDP, rs * 32, nt * 16, c.lane);
-          unsigned ba = tr_addr(c.Q, LDP, rs * 32, kg * 64, c.lane);
-          unsigned aa1 = aa + 4u * LDP * 2u, ba1 = ba + 4u * LDP * 2u;
-          bf16x4 a0, a1, b0[4], b1[4];
-          NM_TR_READ(a0, aa, 0); NM_TR_READ(a1, aa1, 0);
-          NM_TR_READ(b0[0], ba, 0);  NM_TR_READ(b1[0], ba1, 0);
-          NM_TR_READ(b0[1], ba, 32); NM_TR_READ(b1[1], ba1, 32);
-          NM_TR_READ(b0[2], ba, 64); NM_TR_READ(b1[2], ba1, 64);
-          NM_TR_READ(b0[3], ba, 96); NM_TR_READ(b1[3], ba1, 96);
+          unsigned na = tr_addr(c.P, LDP, rs * 32, nt * 16, c.lane);
+          unsigned ka = tr_addr(c.Q, LDP, rs * 32, kp * 32, c.lane);
+          unsigned na1 = na + 4u * LDP * 2u, ka1 = ka + 4u * LDP * 2u;
+          bf16x4 n0v, n1v, k0v[2], k1v[2];
+          NM_TR_READ(n0v, na, 0); NM_TR_READ(n1v, na1, 0);
+          NM_TR_READ(k0v[0], ka, 0);  NM_TR_READ(k1v[0], ka1, 0);
+          NM_TR_READ(k0v[1], ka, 32); NM_TR_READ(k1v[1], ka1, 32);
           asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]),
-                         "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]));
-          a = join4(a0, a1);
-          for (int t = 0; t < 4; ++t) b[t] = join4(b0[t], b1[t]);
+                       : "+v"(n0v), "+v"(n1v), "+v"(k0v[0]), "+v"(k1v[0]), "+v"(k0v[1]), "+v"(k1v[1]));
+          bn = join4(n0v, n1v);
+          for (int t = 0; t < 2; ++t) ak[t] = join4(k0v[t], k1v[t]);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma(a, b[t], acc[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = mfma(ak[t], bn, acc[t]);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        int k = (kg * 4 + t) * 16 + c.c16;
+      for (int t = 0; t < 2; ++t) {
+        int n = nt * 16 + c.c16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int n = nt * 16 + 4 * c.g + i;
+          int k = (kp * 2 + t) * 16 + 4 * c.g + i;
           if (n < N && k < K) Cout[(int64_t)n * K + k] = acc[t][i];
         }
       }
@@ -1273,16 +1332,14 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
   }
 }
 
-constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (64 + 128 + 256) * 4;
-
 }  // namespace
 
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 1; }
+int nm_version(void) { return 2; }
 
-/* phase profile (NM_F_PROFILE = 16): read / reset the per-phase shader-clock accumulators */
+/* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {
   if (!out32) return -1;
   hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(nm_prof_cycles), sizeof(unsigned long long) * 32);
@@ -1310,9 +1367,10 @@ const char* nm_status_string(int status) {
     case -4: return "hidden width out of range (1..NM_MAX_WIDTH)";
     case -5: return "latent out of range (1..NM_MAX_LATENT)";
     case -6: return "latent + c_dim exceeds NM_MAX_WIDTH";
-    case -7: return "table pitch Kx must be a multiple of 32 and >= D + C + 1";
+    case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D";
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
+    case -10: return "parameter tensor offsets must be multiples of 4 floats";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
   }
 }
@@ -1329,6 +1387,10 @@ int nm_validate_job(const nm_job_t* j) {
   for (int m = 0; m < j->M; ++m) {
     const nm_modality_t& md = j->mod[m];
     if (md.Kx % 32 != 0 || md.Kx < md.D + j->C + 1) return -7;
+    if (md.x_pitch % 4 != 0 || md.x_pitch < md.D) return -7;
+    for (int i = 0; i < j->L; ++i)
+      if ((md.enc_w[i] | md.enc_b[i] | md.dec_w[i] | md.dec_b[i]) & 3) return -10;
+    if ((md.mu_w | md.mu_b | md.lv_w | md.lv_b | md.logvar_out | md.out_w | md.out_b) & 3) return -10;
   }
   return 0;
 }
@@ -1394,14 +1456,15 @@ int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t 
 }
 
 int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx, uint16_t* xb,
-                  float* x_f32_out, void* stream) {
+                  float* x_f32_out, int x_pitch, void* stream) {
   if (!x || !xb || (C > 0 && !c)) return -1;
   if (Kx % 32 != 0 || Kx < D + C + 1 || rows_alloc < n_rows || rows_alloc % NM_BATCH != 0) return -7;
+  if (x_f32_out && (x_pitch % 4 != 0 || x_pitch < D || x_pitch > Kx)) return -7;
   int64_t total = (int64_t)rows_alloc * Kx;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, c, n_rows, rows_alloc, D, C,
-                     Kx, xb, x_f32_out);
+                     Kx, xb, x_f32_out, x_pitch);
   return (int)hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ class Table:
 
     ``x`` [N, D] and covariates ``c`` [N, C] (any float/int dtype; the reference's
     ``torch.cat((x, c))`` promotes to float32, cVAE.py:163) become
-      x_f32 [rows_alloc, D]  fp32, zero rows beyond N        (residual / NLL side)
+      x_f32 [rows_alloc, x_pitch] fp32, zero rows beyond N, pitch = D rounded up to 4 (residual / NLL side)
       xb    [rows_alloc, Kx] bf16  x | c | 1 | 0             (MFMA operand side)
     with rows_alloc a multiple of 256 and Kx a multiple of 32.
     """
@@ -53,11 +53,12 @@ class Table:
         self.Kx = (self.D + self.C + 1 + 31) // 32 * 32
         xs = x.to(device=dev, dtype=torch.float32).contiguous()
         cs = c.to(device=dev, dtype=torch.float32).contiguous()
-        self.x_f32 = torch.empty(self.rows_alloc, self.D, dtype=torch.float32, device=dev)
+        self.x_pitch = (self.D + 3) // 4 * 4
+        self.x_f32 = torch.empty(self.rows_alloc, self.x_pitch, dtype=torch.float32, device=dev)
         self.xb = torch.empty(self.rows_alloc, self.Kx, dtype=torch.bfloat16, device=dev)
         _lib.check(lib.nm_pack_table(xs.data_ptr(), cs.data_ptr() if self.C > 0 else None, self.N, self.rows_alloc,
                                      self.D, self.C, self.Kx, self.xb.data_ptr(), self.x_f32.data_ptr(),
-                                     _stream_ptr(dev)), "nm_pack_table")
+                                     self.x_pitch, _stream_ptr(dev)), "nm_pack_table")
         self.device = dev
 
     @property
@@ -187,7 +188,7 @@ class Job:
         j.out_z = self.out_z.data_ptr() if self.out_z is not None else None
         for m, t in enumerate(self.tables):
             md = j.mod[m]
-            md.D, md.Kx = t.D, t.Kx
+            md.D, md.Kx, md.x_pitch = t.D, t.Kx, t.x_pitch
             md.x_f32, md.xb = t.x_f32.data_ptr(), t.xb.data_ptr()
             self.layout.fill_modality(md, m)
             md.out_loc = self.out_loc[m].data_ptr() if self.out_loc[m] is not None else None

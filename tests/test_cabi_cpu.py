@@ -44,6 +44,7 @@ def _probe(M=1, L=2, Z=10, C_=29, H=(110, 110), D=379):
     for m in range(min(M, _lib.NM_MAX_MOD)):
         j.mod[m].D = D
         j.mod[m].Kx = (D + C_ + 1 + 31) // 32 * 32
+        j.mod[m].x_pitch = (D + 3) // 4 * 4
     return j
 
 
