@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--subjects", type=int, default=1280)
     args = ap.parse_args()
 
+    T0 = time.perf_counter()
     import torch
     import multi_modal_normative_modeling_amd as nm
     from multi_modal_normative_modeling_amd import prep, workload
@@ -57,9 +58,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
     # ---- workload: resident in HBM before timing ----
     cohort = prep.synthetic_cohort(n=args.subjects, d=379)
+    log("synthetic cohort ready")
     jobs = workload.build_sweep_jobs(cohort, args.procedure, 5, args.jobs, dev, seed0=rank * args.jobs)
+    log(f"{len(jobs)} jobs resident on {dev}")
     js = nm.JobSet(jobs)
     spec = jobs[0].spec
     work = workload.step_work(spec.input_dims)
@@ -86,6 +93,7 @@ def main():
 
     run_steps(args.warmup)
     barrier()
+    log("warmup done")
     events = []
     t0 = time.perf_counter()
     run_steps(args.steps, events)
@@ -97,6 +105,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log(f"timed region done: {elapsed:.3f}s")
     # sanity: training really happened and stayed finite
     losses = jobs[0].loss_log.cpu()
     if not torch.isfinite(losses).all():

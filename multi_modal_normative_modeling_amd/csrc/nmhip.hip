@@ -1,6 +1,6 @@
 // nmhip.hip -- conditional-VAE train step / forward / deviation pass for MI355X (gfx950, CDNA4).
 //
-// One 512-thread workgroup (8 wavefronts of 64 lanes, two per SIMD) owns one model ("job") and
+// One 512-thread workgroup (8 wavefronts of 64 lanes, two per SIMD: 256 VGPRs each) owns one model ("job") and
 // runs whole train steps for it: encoder MLPs -> expert fusion -> reparameterisation -> decoder
 // MLPs -> Gaussian NLL + KL -> backward -> Adam, with no inter-workgroup communication.  The
 // sweep fills the chip with independent jobs (one workgroup per CU), see DESIGN.md.
@@ -34,8 +34,12 @@
 
 namespace {
 
-constexpr int WG = 512;          // threads per workgroup
-constexpr int NWAVES = 8;
+constexpr int NWM = 2;           // wave grid: row groups
+constexpr int NWN = 4;           //            feature-tile groups
+constexpr int NWAVES = NWM * NWN;
+constexpr int WG = NWAVES * 64;  // threads per workgroup
+constexpr int RT = NM_BATCH / (NWM * 16);   // 16-row tiles per wave
+constexpr int WROWS = RT * 16;   // rows per wave
 constexpr int ROWS = NM_BATCH;   // 256 rows per tile
 constexpr int PW = 128;          // padded feature width held in P/Q
 constexpr int LDP = 136;         // P/Q row pitch (elements): +8 breaks the 256-B bank period
@@ -82,10 +86,11 @@ struct Ctx {
 
 __host__ __device__ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int wpad(int n) { return rup(n + 1, 32); }   // width incl. the ones column
+__host__ __device__ inline int kpitch(int K) { return rup(K, 8); }      // row pitch of a weight matrix in the flat buffer
 
 // ---- workspace layout (shared by host and device) ------------------------------------------
 struct WsLayout {
-  int64_t mu_m, lv_m, mu_j, lv_j, es, dz, enc_act, dec_act, total;
+  int64_t mu_m, lv_m, mu_j, lv_j, es, dz, enc_act, dec_act, zc, total;
   int Zs;
 };
 __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
@@ -102,6 +107,7 @@ __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
   int64_t act = (int64_t)ROWS * PW * 2;
   w.enc_act = o; o += act * M * L;
   w.dec_act = o; o += act * L;
+  w.zc = o; o += act;
   w.total = (o + 255) / 256 * 256;
   return w;
 }
@@ -110,7 +116,7 @@ __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
 enum { PH_ENC_L0 = 0, PH_ENC_REST, PH_HEADS, PH_LATENT, PH_DEC_ZC, PH_DEC_HID, PH_OUT_GEMM, PH_OUT_DLV, PH_OUT_DGRAD,
        PH_OUT_WGRAD, PH_NLL_RED, PH_DEC_FINISH, PH_DEC_LOAD, PH_DEC_DGRAD, PH_DEC_WGRAD, PH_DEC_DELTA, PH_ALPHA,
        PH_ENCB_PREP, PH_ENCB_HEADS_DGRAD, PH_ENCB_HEADS_WGRAD, PH_ENCB_LOAD, PH_ENCB_DGRAD, PH_ENCB_WGRAD,
-       PH_ENCB_DELTA, PH_ENCB_L0_WGRAD, PH_COUNT };
+       PH_ENCB_DELTA, PH_ENCB_L0_WGRAD, PH_X_LOADS, PH_X_MFMA, PH_X_EPI, PH_COUNT };
 __device__ __forceinline__ void prof(Ctx& c, int phase) {
   if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     unsigned long long t = clock64();
@@ -130,8 +136,8 @@ __device__ __forceinline__ void relaunder(Ctx& c) {
   c.lane = t & 63;
   int w = __builtin_amdgcn_readfirstlane(t >> 6);
   c.wave = w;
-  c.wm = w >> 2;
-  c.wn = w & 3;
+  c.wm = w / NWN;
+  c.wn = w % NWN;
   c.g = c.lane >> 4;
   c.c16 = c.lane & 15;
 }
@@ -196,41 +202,28 @@ __device__ __forceinline__ bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, 
   return r;
 }
 
-// Forward weight fragment: W[n][k0 .. k0+7] (fp32, row-major [N][K]) -> bf16x8, zero outside.
+// Weight matrices live in the flat parameter buffer as [N][kpitch(K)] fp32 (rows padded to a
+// multiple of 8 with zeros, every row 32-byte aligned), so a fragment is always two 16-byte loads.
+// Forward weight fragment: W[n][k0 .. k0+7] -> bf16x8, zero outside.
 __device__ __forceinline__ bf16x8 w_frag(gcf32 W, int N, int K, int n, int k0) {
+  const int Kp = kpitch(K);
+  const GAS f32x4* p = (const GAS f32x4*)(W + (int64_t)min(n, N - 1) * Kp + min(k0, Kp - 8));
+  f32x4 a = p[0], b = p[1];
+  const bool ok = (n < N) && (k0 < Kp);            // pad columns are zeros in memory
   bf16x8 r;
-  gcf32 src = W + (int64_t)n * K + k0;
-  const bool inside = n < N && k0 + 8 <= K;
-  if (inside && (((uintptr_t)src & 15) == 0)) {
-    const GAS f32x4* p = (const GAS f32x4*)src;
-    f32x4 a = p[0], b = p[1];
-    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
-    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
-  } else if (inside && (((uintptr_t)src & 7) == 0)) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    const GAS f32x2* p = (const GAS f32x2*)src;
-    f32x2 a = p[0], b = p[1], c2 = p[2], d = p[3];
-    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)b[0]; r[3] = (__bf16)b[1];
-    r[4] = (__bf16)c2[0]; r[5] = (__bf16)c2[1]; r[6] = (__bf16)d[0]; r[7] = (__bf16)d[1];
-  } else {
-    // unconditional loads from clamped (always valid) addresses, then select: no branch, all 8 in flight
-    const int nc = min(n, N - 1);
-    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)nc * K + min(k0 + j, K - 1)];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)((n < N && k0 + j < K) ? v[j] : 0.f);
-  }
+  for (int j = 0; j < 4; ++j) { r[j] = (__bf16)(ok ? a[j] : 0.f); r[4 + j] = (__bf16)(ok ? b[j] : 0.f); }
   return r;
 }
 
 // Dgrad weight fragment: W[n0 + j][k] for j = 0..7 (contraction over the OUTPUT index n).
 __device__ __forceinline__ bf16x8 w_frag_t(gcf32 W, int N, int K, int n0, int k) {
+  const int Kp = kpitch(K);
   bf16x8 r;
-  const int kc = min(k, K - 1);
+  const int kc = min(k, Kp - 1);
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)min(n0 + j, N - 1) * K + kc];
+  for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)min(n0 + j, N - 1) * Kp + kc];
 #pragma unroll
   for (int j = 0; j < 8; ++j) r[j] = (__bf16)((n0 + j < N && k < K) ? v[j] : 0.f);
   return r;
@@ -289,27 +282,12 @@ __device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g) {
   }
 }
 
-// 4 consecutive parameters (16-byte aligned): the unit of the coalesced sweep
-__device__ __forceinline__ void apply_grad_vec4(const Ctx& c, int64_t idx, f32x4 g) {
-  const nm_job_t* J = c.job;
-  if (c.flags & NM_F_GRADS) *(GAS f32x4*)(asg(J->grads) + idx) = g;
-  if (c.flags & NM_F_ADAM) {
-    GAS f32x4* P_ = (GAS f32x4*)(asg(J->params) + idx);
-    GAS f32x4* M_ = (GAS f32x4*)(asg(J->adam_m) + idx);
-    GAS f32x4* V_ = (GAS f32x4*)(asg(J->adam_v) + idx);
-    f32x4 p = *P_, m = *M_, v = *V_;
-    const AdamK a = adam_consts(c);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { float pp = p[i], mm = m[i], vv = v[i]; adam1(a, g[i], pp, mm, vv); p[i] = pp; m[i] = mm; v[i] = vv; }
-    *P_ = p; *M_ = m; *V_ = v;
-  }
-}
-
 // ---- cooperative copies ----------------------------------------------------------------------
 // global bf16 [256][PW] (saved activation) <-> LDS [256][LDP]; only the first `width` columns move
 __device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src, int width) {
   const int segs = width >> 3;                   // 16-byte pieces per row (width is a multiple of 32)
   const float rs = 1.0f / (float)segs;
+#pragma unroll 4
   for (int p = c.tid; p < ROWS * segs; p += WG) {
     int row = idiv(p, segs, rs), seg = p - row * segs;
     u32x4 v = *(const GAS u32x4*)(src + row * PW + seg * 8);
@@ -319,6 +297,7 @@ __device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src, 
 __device__ __forceinline__ void store_act(const Ctx& c, gbf16 dst, const __bf16* src, int width) {
   const int segs = width >> 3;
   const float rs = 1.0f / (float)segs;
+#pragma unroll 4
   for (int p = c.tid; p < ROWS * segs; p += WG) {
     int row = idiv(p, segs, rs), seg = p - row * segs;
     u32x4 v = *reinterpret_cast<const u32x4*>(src + row * LDP + seg * 8);
@@ -327,10 +306,11 @@ __device__ __forceinline__ void store_act(const Ctx& c, gbf16 dst, const __bf16*
 }
 
 // one 64-column chunk of the packed table xb into registers / into Q (pitch LDX)
-struct XStage { u32x4 v[4]; };
+constexpr int XPIECES = (ROWS * XCH / 8) / WG;     // 16-byte pieces of an x chunk per thread
+struct XStage { u32x4 v[XPIECES]; };
 __device__ __forceinline__ void xchunk_load(const Ctx& c, XStage& s, const GAS uint16_t* xb, int Kx, int kc) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < XPIECES; ++i) {
     int p = c.tid + i * WG;            // 2048 pieces of 16 B
     int row = p >> 3, seg = p & 7;
     int col = kc * XCH + seg * 8;
@@ -341,40 +321,44 @@ __device__ __forceinline__ void xchunk_load(const Ctx& c, XStage& s, const GAS u
 }
 __device__ __forceinline__ void xchunk_store(const Ctx& c, const XStage& s, __bf16* Q) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < XPIECES; ++i) {
     int p = c.tid + i * WG;
     int row = p >> 3, seg = p & 7;
     *reinterpret_cast<u32x4*>(Q + row * LDX + seg * 8) = s.v[i];
   }
 }
 
-// [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer
+// [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer.  Two branch-free
+// passes (clamped, unconditional loads): the covariate/ones/pad columns from the packed table (its
+// columns D .. D+C hold c | 1), then the z columns from the latent workspace.
 __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_modality_t& md, gcf32 mu_j, gcf32 es, int Z,
                                          int C, int Zs) {
-  const int Kd0 = Z + C, wz = wpad(Kd0);
-  const float rw = 1.0f / (float)wz;
+  const int wz = wpad(Z + C), wc = wz - Z;
+  const float rwc = 1.0f / (float)wc, rz = 1.0f / (float)Z;
   gcbf16 xb = (gcbf16)asg(md.xb);
 #pragma unroll 4
-  for (int e = c.tid; e < ROWS * wz; e += WG) {
-    int r = idiv(e, wz, rw), k = e - r * wz;
-    float v;
-    if (k < Z) v = mu_j[r * Zs + k] + es[r * Zs + k];
-    else if (k < Kd0) v = (float)xb[(int64_t)(c.row0 + r) * md.Kx + md.D + (k - Z)];
-    else v = (k == Kd0) ? 1.0f : 0.0f;
-    dst[r * LDP + k] = (__bf16)v;
+  for (int e = c.tid; e < ROWS * wc; e += WG) {
+    int r = idiv(e, wc, rwc), j = e - r * wc;
+    __bf16 v = xb[(int64_t)(c.row0 + r) * md.Kx + md.D + min(j, C)];
+    dst[r * LDP + Z + j] = (j <= C) ? v : (__bf16)0.0f;
+  }
+#pragma unroll 4
+  for (int e = c.tid; e < ROWS * Z; e += WG) {
+    int r = idiv(e, Z, rz), k = e - r * Z;
+    dst[r * LDP + k] = (__bf16)(mu_j[r * Zs + k] + es[r * Zs + k]);
   }
 }
 
 // ---- accumulator tile bookkeeping --------------------------------------------------------------
 // acc[t][rt]: feature tile ft = wn + 4 t, row tile rt; lane holds features ft*16 + 4g + i (i = 0..3)
 // of row wm*128 + rt*16 + c16.
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][8]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][RT]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ void bias_acc(const Ctx& c, f32x4 (&acc)[2][8], gcf32 b, int N, int f_base) {
+__device__ __forceinline__ void bias_acc(const Ctx& c, f32x4 (&acc)[2][RT], gcf32 b, int N, int f_base) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     int f0 = f_base + (c.wn + 4 * t) * 16 + 4 * c.g;
@@ -382,19 +366,19 @@ __device__ __forceinline__ void bias_acc(const Ctx& c, f32x4 (&acc)[2][8], gcf32
 #pragma unroll
     for (int i = 0; i < 4; ++i) { float x = b[min(f0 + i, N - 1)]; bv[i] = (f0 + i < N) ? x : 0.f; }
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) acc[t][rt] = bv;
+    for (int rt = 0; rt < RT; ++rt) acc[t][rt] = bv;
   }
 }
 // activation epilogue: P[r][f] = act(acc) for f < N, 1 at f == N (ones column), 0 beyond
-__device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][8], int N, int ntn, bool act) {
+__device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT], int N, int ntn, bool act) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     int ft = c.wn + 4 * t;
     if (ft >= ntn) continue;
     int f0 = ft * 16 + 4 * c.g;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      int r = c.wm * 128 + rt * 16 + c.c16;
+    for (int rt = 0; rt < RT; ++rt) {
+      int r = c.wm * WROWS + rt * 16 + c.c16;
       bf16x4 pk;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -415,27 +399,27 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
                                                   gbf16 save) {
   Ctx c = cc;
   relaunder(c);
-  const int ksteps = wpad(K) / 32;
+  const int ksteps = wpad(K) / 32;       // <= 4
   const int ntn = wpad(N) / 16;
-  f32x4 acc[2][8];
+  // every weight fragment of the layer first: 16 x 16-byte loads in flight per lane
+  bf16x8 wf[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      wf[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+  f32x4 acc[2][RT];
   bias_acc(c, acc, b, N, 0);
-  bf16x8 wcur[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) wcur[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, 8 * c.g);
-  for (int ks = 0; ks < ksteps; ++ks) {
-    bf16x8 wnext[2];
-    if (ks + 1 < ksteps) {
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks < ksteps) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wnext[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (ks + 1) * 32 + 8 * c.g);
+      for (int rt = 0; rt < RT; ++rt) {
+        bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ks][t], a, acc[t][rt]);
+      }
     }
-#pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if ((c.wn + 4 * t) < ntn) acc[t][rt] = mfma(wcur[t], a, acc[t][rt]);
-    }
-    if (ks + 1 < ksteps) { wcur[0] = wnext[0]; wcur[1] = wnext[1]; }
   }
   __syncthreads();                       // every wave has finished reading P
   act_to_P(c, acc, N, ntn, act);
@@ -451,29 +435,43 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
   const int Kx = md.Kx;
   const int nch = (Kx + XCH - 1) / XCH;
   const int ntn = wpad(N) / 16;
-  f32x4 acc[2][8];
+  f32x4 acc[2][RT];
   bias_acc(c, acc, b, N, 0);
   XStage st;
+  bf16x8 wf[2][2];
   xchunk_load(c, st, asg(md.xb), Kx, 0);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wf[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
   for (int kc = 0; kc < nch; ++kc) {
     xchunk_store(c, st, c.Q);
     __syncthreads();
-    if (kc + 1 < nch) xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
+    bf16x8 wn[2][2];
+    if (kc + 1 < nch) {                   // next chunk's inputs and weights fly during this chunk's MFMAs
+      xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          wn[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (kc + 1) * XCH + ks * 32 + 8 * c.g);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      int kg = kc * XCH + ks * 32;
-      if (kg < Kx) {
-        bf16x8 wf[2];
+      if (kc * XCH + ks * 32 < Kx) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) wf[t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, kg + 8 * c.g);
+        for (int rt = 0; rt < RT; ++rt) {
+          bf16x8 a = lds_frag(c.Q, LDX, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-          bf16x8 a = lds_frag(c.Q, LDX, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            if ((c.wn + 4 * t) < ntn) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+          for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ks][t], a, acc[t][rt]);
         }
       }
+    }
+    if (kc + 1 < nch) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[ks][t] = wn[ks][t];
     }
     __syncthreads();
   }
@@ -491,7 +489,7 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, g
   const int nzt = Zs / 16;
   for (int ft = c.wn; ft < nzt; ft += 4) {
     const int f0 = ft * 16 + 4 * c.g;
-    f32x4 am[8], al[8];
+    f32x4 am[RT], al[RT];
     f32x4 b0, b1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -500,20 +498,27 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, g
       b1[i] = (f0 + i < Z) ? x1 : 0.f;
     }
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) { am[rt] = b0; al[rt] = b1; }
-    for (int ks = 0; ks < ksteps; ++ks) {
-      bf16x8 fm = w_frag(Wmu, Z, K, ft * 16 + c.c16, ks * 32 + 8 * c.g);
-      bf16x8 fl = w_frag(Wlv, Z, K, ft * 16 + c.c16, ks * 32 + 8 * c.g);
+    for (int rt = 0; rt < RT; ++rt) { am[rt] = b0; al[rt] = b1; }
+    bf16x8 fm[4], fl[4];
 #pragma unroll
-      for (int rt = 0; rt < 8; ++rt) {
-        bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
-        am[rt] = mfma(fm, a, am[rt]);
-        al[rt] = mfma(fl, a, al[rt]);
+    for (int ks = 0; ks < 4; ++ks) {
+      fm[ks] = w_frag(Wmu, Z, K, ft * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+      fl[ks] = w_frag(Wlv, Z, K, ft * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < ksteps) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+          am[rt] = mfma(fm[ks], a, am[rt]);
+          al[rt] = mfma(fl[ks], a, al[rt]);
+        }
       }
     }
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      int r = c.wm * 128 + rt * 16 + c.c16;
+    for (int rt = 0; rt < RT; ++rt) {
+      int r = c.wm * WROWS + rt * 16 + c.c16;
       *(GAS f32x4*)(mu_out + r * Zs + f0) = am[rt];      // features >= Z are exactly 0 (masked weights, zero bias)
       *(GAS f32x4*)(lv_out + r * Zs + f0) = al[rt];
     }
@@ -524,32 +529,36 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, g
 // ---- dgrad: acc[k][r] += sum_n A[r][n] W[n][k]  (contraction over the columns of A) ------------
 // k tiles {wn, wn+4} of wpad(K); nsteps = 32-wide steps over A's columns; n_base = index of A's
 // column 0 in W's row space.
-__device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][8], const __bf16* A, gcf32 W, int N, int K,
+__device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][RT], const __bf16* A, gcf32 W, int N, int K,
                                           int nsteps, int n_base) {
   Ctx c = cc;
   relaunder(c);
-  const int ntk = wpad(K) / 16;
-  for (int s = 0; s < nsteps; ++s) {
-    bf16x8 wf[2];
+  for (int s0 = 0; s0 < nsteps; s0 += 2) {
+    bf16x8 wf[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-      wf[t] = w_frag_t(W, N, K, n_base + s * 32 + 8 * c.g, (c.wn + 4 * t) * 16 + c.c16);
-#pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      bf16x8 a = lds_frag(A, LDP, c.wm * 128 + rt * 16 + c.c16, s * 32 + 8 * c.g);
+    for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        if ((c.wn + 4 * t) < ntk) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+        wf[ss][t] = w_frag_t(W, N, K, n_base + min(s0 + ss, nsteps - 1) * 32 + 8 * c.g, (c.wn + 4 * t) * 16 + c.c16);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      if (s0 + ss < nsteps) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          bf16x8 a = lds_frag(A, LDP, c.wm * WROWS + rt * 16 + c.c16, (s0 + ss) * 32 + 8 * c.g);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ss][t], a, acc[t][rt]);
+        }
+      }
     }
   }
 }
 
 // dgrad through the two encoder heads: P columns [0,Zs) = d mu, [Zs,2Zs) = d logvar
-__device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[2][8], gcf32 Wmu, gcf32 Wlv, int Z, int K,
+__device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[2][RT], gcf32 Wmu, gcf32 Wlv, int Z, int K,
                                             int Zs) {
   Ctx c = cc;
   relaunder(c);
-  const int ntk = wpad(K) / 16;
   const int nsteps = rup(2 * Zs, 32) / 32;
   for (int s = 0; s < nsteps; ++s) {
     bf16x8 wf[2];
@@ -560,17 +569,16 @@ __device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[2][8], g
       wf[t] = (nn0 < Zs) ? w_frag_t(Wmu, Z, K, nn0, k) : w_frag_t(Wlv, Z, K, nn0 - Zs, k);
     }
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, s * 32 + 8 * c.g);
+    for (int rt = 0; rt < RT; ++rt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, s * 32 + 8 * c.g);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if ((c.wn + 4 * t) < ntk) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+      for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
     }
   }
 }
 
 // P[r][k] = acc[k][r] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
-__device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2][8], const __bf16* src, int K,
+__device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2][RT], const __bf16* src, int K,
                                              bool act) {
   Ctx c = cc;
   relaunder(c);
@@ -581,8 +589,8 @@ __device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2
     if (kt >= ntk) continue;
     int k0 = kt * 16 + 4 * c.g;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      int r = c.wm * 128 + rt * 16 + c.c16;
+    for (int rt = 0; rt < RT; ++rt) {
+      int r = c.wm * WROWS + rt * 16 + c.c16;
       bf16x4 a = *reinterpret_cast<const bf16x4*>(src + r * LDP + k0);
       bf16x4 pk;
 #pragma unroll
@@ -600,101 +608,102 @@ __device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2
 // ---- wgrad + Adam ------------------------------------------------------------------------------
 // dW[n][k] = sum_r A[r][a_col0 + n] * B[r][kk], n in [0,N), B columns kk in [0, ncols) map to the
 // weight column k = k_base + kk; k < K is W[n][k], k == K the bias b[n] (ones column), beyond:
-// nothing.  The output is produced in slabs of SR rows x SC columns (32 x 128 or 64 x 64): the 8
-// waves write their accumulator tiles (4 consecutive k per lane, 16 bytes) into the LDS slab S,
-// then all 512 threads sweep the slab's parameter range with 16-byte p/m/v accesses.
+// nothing.  The output is produced in slabs of SR rows x SC columns (32 x 128 or 64 x 64, = one
+// 16-byte parameter group per thread).  Per slab every thread first ISSUES the loads of its group's
+// p/m/v (so their HBM latency hides under the MFMA work), the 16 waves then write their accumulator
+// tiles (4 consecutive k per lane) into the LDS slab S, and after one barrier every thread applies
+// Adam to its group with 16-byte stores: the sweep walks contiguous parameter memory.
 template <bool SCALAR_TR>
 __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
                                            int N, int K, int k_base, int ncols, int64_t w_off, int64_t b_off) {
   Ctx c = cc;
   relaunder(c);
+  const nm_job_t* J = c.job;
   const bool wide = ncols > 64;                 // slab shape
   const int SR = wide ? 32 : 64, SP = (wide ? 128 : 64) + 4;      // slab rows, slab pitch (floats)
+  const int Kp = kpitch(K);
   const int nkt = (ncols + 15) / 16;            // k tiles in this pass
-  const int kpairs = (nkt + 1) / 2;
-  const int ncv = max(0, min(ncols, K - k_base));               // weight columns in this pass
+  const int gpr = max(0, min(ncols, Kp - k_base)) >> 2;          // 16-byte parameter groups per row in this pass
+  const float rg = gpr > 0 ? 1.0f / (float)gpr : 0.f;
   const bool has_bias = (K >= k_base) && (K < k_base + ncols);
-  const bool contig = (k_base == 0) && (ncv == K);              // slab rows are whole weight rows
+  const bool do_adam = (c.flags & NM_F_ADAM) != 0;
+  const AdamK ak = adam_consts(c);
+  constexpr int NG = 1024 / WG;                 // 16-byte parameter groups per thread and slab
   for (int n0 = 0; n0 < N; n0 += SR) {
     const int nr = min(SR, N - n0);
     const int nts = (nr + 15) / 16;
-    // ---- tiles -> slab ----
-    for (int u = c.wave; u < nts * kpairs; u += NWAVES) {
-      const int nt = u / kpairs, kp = u - nt * kpairs;
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // ---- this thread's parameter groups: issue the p/m/v loads now ----
+    bool mine[NG];
+    int qn[NG], qk[NG];
+    int64_t pidx[NG];
+    f32x4 pv[NG], mv[NG], vv[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int q = c.tid + j * WG;
+      mine[j] = q < nr * gpr;
+      qn[j] = mine[j] ? idiv(q, gpr, rg) : 0;
+      qk[j] = mine[j] ? (q - qn[j] * gpr) * 4 : 0;                              // column inside the pass
+      pidx[j] = w_off + (int64_t)(n0 + qn[j]) * Kp + k_base + qk[j];            // 16-byte aligned
+      pv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; mv[j] = pv[j]; vv[j] = pv[j];
+      if (do_adam && mine[j]) {
+        pv[j] = *(const GAS f32x4*)(asg(J->params) + pidx[j]);
+        mv[j] = *(const GAS f32x4*)(asg(J->adam_m) + pidx[j]);
+        vv[j] = *(const GAS f32x4*)(asg(J->adam_v) + pidx[j]);
+      }
+    }
+    // ---- tiles -> slab (one 16x16 tile per wave and turn) ----
+    for (int u = c.wave; u < nts * nkt; u += NWAVES) {
+      const int nt = u / nkt, kt = u - nt * nkt;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int ncol = a_col0 + n0 + nt * 16;
       if (SCALAR_TR) {
         for (int rs = 0; rs < ROWS / 32; ++rs) {
           bf16x8 bn = lds_frag_tr_scalar(A, lda, rs * 32, ncol, c.lane);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            bf16x8 ak = lds_frag_tr_scalar(B, ldb, rs * 32, (kp * 2 + t) * 16, c.lane);
-            acc[t] = mfma(ak, bn, acc[t]);
-          }
+          bf16x8 akf = lds_frag_tr_scalar(B, ldb, rs * 32, kt * 16, c.lane);
+          acc = mfma(akf, bn, acc);
         }
       } else {
         unsigned na = tr_addr(A, lda, 0, ncol, c.lane);
-        unsigned ka = tr_addr(B, ldb, 0, kp * 32, c.lane);
+        unsigned ka = tr_addr(B, ldb, 0, kt * 16, c.lane);
         const unsigned n_step = 32u * lda * 2u, k_step = 32u * ldb * 2u;
         const unsigned n4 = 4u * lda * 2u, k4 = 4u * ldb * 2u;
 #pragma unroll 2
-        for (int rs = 0; rs < ROWS / 32; ++rs) {
-          bf16x4 n0v, n1v, k0v[2], k1v[2];
-          unsigned na1 = na + n4, ka1 = ka + k4;
-          NM_TR_READ(n0v, na, 0);
-          NM_TR_READ(n1v, na1, 0);
-          NM_TR_READ(k0v[0], ka, 0);  NM_TR_READ(k1v[0], ka1, 0);
-          NM_TR_READ(k0v[1], ka, 32); NM_TR_READ(k1v[1], ka1, 32);
+        for (int rs = 0; rs < ROWS / 32; rs += 2) {
+          // two row steps per wait: 8 transposing reads in flight
+          bf16x4 n0v, n1v, k0v, k1v, n2v, n3v, k2v, k3v;
+          unsigned na1 = na + n4, ka1 = ka + k4, na2 = na + n_step, ka2 = ka + k_step;
+          unsigned na3 = na2 + n4, ka3 = ka2 + k4;
+          NM_TR_READ(n0v, na, 0);  NM_TR_READ(n1v, na1, 0);
+          NM_TR_READ(k0v, ka, 0);  NM_TR_READ(k1v, ka1, 0);
+          NM_TR_READ(n2v, na2, 0); NM_TR_READ(n3v, na3, 0);
+          NM_TR_READ(k2v, ka2, 0); NM_TR_READ(k3v, ka3, 0);
           asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(n0v), "+v"(n1v), "+v"(k0v[0]), "+v"(k1v[0]), "+v"(k0v[1]), "+v"(k1v[1]));
-          bf16x8 bn = join4(n0v, n1v);
-          acc[0] = mfma(join4(k0v[0], k1v[0]), bn, acc[0]);
-          acc[1] = mfma(join4(k0v[1], k1v[1]), bn, acc[1]);
-          na += n_step; ka += k_step;
+                       : "+v"(n0v), "+v"(n1v), "+v"(k0v), "+v"(k1v), "+v"(n2v), "+v"(n3v), "+v"(k2v), "+v"(k3v));
+          acc = mfma(join4(k0v, k1v), join4(n0v, n1v), acc);
+          acc = mfma(join4(k2v, k3v), join4(n2v, n3v), acc);
+          na += 2 * n_step; ka += 2 * k_step;
         }
       }
-      // lane holds dW[n = nt*16 + c16][kk = (kp*2 + t)*16 + 4g .. +3]
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (kp * 2 + t < nkt)
-          *reinterpret_cast<f32x4*>(c.stage + (nt * 16 + c.c16) * SP + (kp * 2 + t) * 16 + 4 * c.g) = acc[t];
+      // lane holds dW[n = nt*16 + c16][kk = kt*16 + 4g .. +3]
+      *reinterpret_cast<f32x4*>(c.stage + (nt * 16 + c.c16) * SP + kt * 16 + 4 * c.g) = acc;
     }
     __syncthreads();
-    // ---- coalesced sweep over the slab's parameters ----
-    if (contig) {
-      const int total = nr * K;
-      const int64_t base = w_off + (int64_t)n0 * K;              // 16-byte aligned: w_off % 4 == 0, n0 % 32 == 0
-      const float rk = 1.0f / (float)K;
-      for (int q = c.tid; q < (total + 3) / 4; q += WG) {
-        int e = 4 * q;
-        int n = idiv(e, K, rk), k = e - n * K;
-        f32x4 g;
+    // ---- Adam on this thread's group; bias column by the first nr threads ----
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          g[i] = c.stage[min(n, nr - 1) * SP + k];
-          ++k;
-          if (k == K) { k = 0; ++n; }
-        }
-        if (e + 4 <= total) apply_grad_vec4(c, base + e, g);
-        else {
+    for (int j = 0; j < NG; ++j) {
+      if (mine[j]) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(c.stage + qn[j] * SP + qk[j]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (e + i < total) apply_grad(c, base + e + i, g[i]);
+        for (int i = 0; i < 4; ++i) g[i] = (k_base + qk[j] + i < K) ? g[i] : 0.f;      // pad columns keep zero gradient
+        if (c.flags & NM_F_GRADS) *(GAS f32x4*)(asg(J->grads) + pidx[j]) = g;
+        if (do_adam) {
+          f32x4 p4 = pv[j], m4 = mv[j], v4 = vv[j];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { float pp = p4[i], mm = m4[i], v2 = v4[i]; adam1(ak, g[i], pp, mm, v2); p4[i] = pp; m4[i] = mm; v4[i] = v2; }
+          *(GAS f32x4*)(asg(J->params) + pidx[j]) = p4;
+          *(GAS f32x4*)(asg(J->adam_m) + pidx[j]) = m4;
+          *(GAS f32x4*)(asg(J->adam_v) + pidx[j]) = v4;
         }
-      }
-    } else if (ncv > 0 && (K & 3) == 0 && (ncv & 3) == 0) {
-      const int gpr = ncv >> 2;                                   // 16-byte groups per row
-      const float rg = 1.0f / (float)gpr;
-      for (int q = c.tid; q < nr * gpr; q += WG) {
-        int n = idiv(q, gpr, rg), k4 = q - n * gpr;
-        f32x4 g = *reinterpret_cast<const f32x4*>(c.stage + n * SP + 4 * k4);
-        apply_grad_vec4(c, w_off + (int64_t)(n0 + n) * K + k_base + 4 * k4, g);
-      }
-    } else if (ncv > 0) {
-      const float rc = 1.0f / (float)ncv;
-      for (int q = c.tid; q < nr * ncv; q += WG) {
-        int n = idiv(q, ncv, rc), k = q - n * ncv;
-        apply_grad(c, w_off + (int64_t)(n0 + n) * K + k_base + k, c.stage[n * SP + k]);
       }
     }
     if (has_bias && c.tid < nr) apply_grad(c, b_off + n0 + c.tid, c.stage[c.tid * SP + (K - k_base)]);
@@ -816,6 +825,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   gf32 ws_dz = (gf32)(c.ws + wl.dz);
   gbf16 ws_enc = (gbf16)(c.ws + wl.enc_act);
   gbf16 ws_dec = (gbf16)(c.ws + wl.dec_act);
+  gbf16 ws_zc = (gbf16)(c.ws + wl.zc);
   gcf32 prm = asg(J->params);
 
   // ================= encoders =================
@@ -883,6 +893,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const int Kd0 = Z + C;
     build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
     __syncthreads();
+    if (bwd) store_act(c, ws_zc, c.P, wpad(Kd0));
     prof(c, PH_DEC_ZC);
     // --- hidden decoder layers ---
     for (int d = 0; d < L; ++d) {
@@ -899,7 +910,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     gcf32 lvo = prm + md.logvar_out;
     gcf32 xf = asg(md.x_f32);
     const int xp = md.x_pitch;
-    f32x4 accg[2][8];
+    f32x4 accg[2][RT];
     zero_acc(accg);
     float nll_part = 0.f;
     if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
@@ -912,64 +923,92 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       __syncthreads();
       // x_hat chunk: acc[d][r]
       {
-        f32x4 acc[2][8];
         const int ksteps = wpad(Hl) / 32;
+        // everything this chunk reads from memory is requested first: weight fragments, the fp32
+        // inputs of the residual (rows are always inside the zero-padded table) and logvar_out
+        bf16x8 wf[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            wf[ks][t] = w_frag(Wo, D, Hl, d0 + (c.wn + 4 * t) * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+        f32x4 xin[RT];                     // inputs of feature tile t = 0 now, t = 1 after tile 0's epilogue
+        float sv[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int dg0 = d0 + (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[t][i] = lvo[min(dg0 + i, D - 1)];
+        }
+        {
+          const int dcl = min(d0 + c.wn * 16 + 4 * c.g, xp - 4);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
+        }
+        prof(c, PH_X_LOADS);
+        f32x4 acc[2][RT];
         bias_acc(c, acc, bo, D, d0);
-        for (int ks = 0; ks < ksteps; ++ks) {
-          bf16x8 wf[2];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) wf[t] = w_frag(Wo, D, Hl, d0 + (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks < ksteps) {
 #pragma unroll
-          for (int rt = 0; rt < 8; ++rt) {
-            bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+            for (int rt = 0; rt < RT; ++rt) {
+              bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+              for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ks][t], a, acc[t][rt]);
+            }
           }
         }
+        prof(c, PH_X_MFMA);
         // epilogue: residual, NLL, d logvar_out, delta chunk -> Q.  Lane: 4 consecutive ROI of one row.
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int dl0 = (c.wn + 4 * t) * 16 + 4 * c.g;       // first of the lane's 4 columns inside the chunk
           const int dg0 = d0 + dl0;
-          float sv[4], inv[4], colsum[4];
+          float inv[4], colsum[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            sv[i] = lvo[min(dg0 + i, D - 1)];
-            inv[i] = expf(-sv[i]);
-            colsum[i] = 0.f;
+          for (int i = 0; i < 4; ++i) { inv[i] = expf(-sv[t][i]); colsum[i] = 0.f; }
+          f32x4 xcur[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) xcur[rt] = xin[rt];
+          if (t == 0) {                      // request tile 1's inputs while tile 0 is processed
+            const int dcl = min(d0 + (c.wn + 4) * 16 + 4 * c.g, xp - 4);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
           }
-          // the 8 rows' inputs first: 8 x 16 bytes in flight (rows are always inside the zero-padded table)
-          f32x4 xin[8];
-          const int dcl = min(dg0, xp - 4);
 #pragma unroll
-          for (int rt = 0; rt < 8; ++rt)
-            xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * 128 + rt * 16 + c.c16) * xp + dcl);
-#pragma unroll
-          for (int rt = 0; rt < 8; ++rt) {
-            const int r = c.wm * 128 + rt * 16 + c.c16;
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = c.wm * WROWS + rt * 16 + c.c16;
             const bool rv = r < c.nrows;
             bf16x4 pk;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const bool ok = rv && (dg0 + i < D);
-              float xh = acc[t][rt][i];
-              float diff = xh - xin[rt][i];
-              float q = diff * diff * inv[i];
-              float delta = 0.f;
-              if (ok) {
-                nll_part += 0.5f * q + 0.5f * sv[i] + LOG_SQRT_2PI;
-                colsum[i] += 0.5f - 0.5f * q;
-                delta = J->ll_weight * diff * inv[i] * c.inv_b;
-                if (exportf) {
+              const float diff = acc[t][rt][i] - xcur[rt][i];
+              const float q = diff * diff * inv[i];
+              nll_part += ok ? (0.5f * q + 0.5f * sv[t][i] + LOG_SQRT_2PI) : 0.f;
+              colsum[i] += ok ? (0.5f - 0.5f * q) : 0.f;
+              pk[i] = (__bf16)(ok ? J->ll_weight * diff * inv[i] * c.inv_b : 0.f);
+            }
+            if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
+          }
+          if (exportf) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              const int r = c.wm * WROWS + rt * 16 + c.c16;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (r < c.nrows && dg0 + i < D) {
+                  const float xh = acc[t][rt][i], diff = xh - xcur[rt][i];
                   int64_t gi = (int64_t)(c.row0 + r) * D + dg0 + i;
                   if (md.out_loc) asg(md.out_loc)[gi] = xh;
                   if (md.out_sqerr) asg(md.out_sqerr)[gi] = diff * diff;
                   if (md.out_rowdev) atomicAdd(&c.rowacc[r], diff * diff);
                 }
               }
-              pk[i] = (__bf16)delta;
             }
-            if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
           }
           if (bwd) {
 #pragma unroll
@@ -984,6 +1023,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           }
         }
       }
+      prof(c, PH_X_EPI);
       if (!bwd) continue;
       __syncthreads();
       prof(c, PH_OUT_GEMM);
@@ -996,7 +1036,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
       wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, rup(Hl + 1, 16),
-                            md.out_w + (int64_t)d0 * Hl, md.out_b + d0);
+                            md.out_w + (int64_t)d0 * kpitch(Hl), md.out_b + d0);
       prof(c, PH_OUT_WGRAD);
     }
     float nll = block_sum(c, nll_part);
@@ -1021,11 +1061,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
       // Q <- input activation of decoder layer d
-      if (d == 0) build_zc(c, c.Q, md, ws_mu_j, ws_es, Z, C, Zs);
-      else load_act(c, c.Q, ws_dec + (int64_t)(d - 1) * ROWS * PW, wpad(Kin));
+      load_act(c, c.Q, d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ROWS * PW, wpad(Kin));
       __syncthreads();
       prof(c, PH_DEC_LOAD);
-      f32x4 acc[2][8];
+      f32x4 acc[2][RT];
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.dec_w[d], Nout, Kin, wpad(Nout) / 32, 0);
       __syncthreads();                              // old weights fully read
@@ -1044,8 +1083,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           int k0 = kt * 16 + 4 * c.g;
           if (k0 < Z) {
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt) {
-              int r = c.wm * 128 + rt * 16 + c.c16;
+            for (int rt = 0; rt < RT; ++rt) {
+              int r = c.wm * WROWS + rt * 16 + c.c16;
               GAS f32x4* p = (GAS f32x4*)(ws_dz + r * Zs + k0);    // columns >= Z of the row are never read
               *p = *p + acc[t][rt];
             }
@@ -1125,7 +1164,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW, wpad(Hh));
     __syncthreads();
     prof(c, PH_ENCB_PREP);
-    f32x4 acc[2][8];
+    f32x4 acc[2][RT];
     zero_acc(acc);
     dgrad_heads(c, acc, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
     __syncthreads();
@@ -1261,7 +1300,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
     int KA = (mode == 0) ? K : N;
     for (int e = c.tid; e < ROWS * KA; e += WG) { int r = e / KA, k = e - r * KA; c.P[r * LDP + k] = (__bf16)A[e]; }
     __syncthreads();
-    f32x4 acc[2][8];
+    f32x4 acc[2][RT];
     zero_acc(acc);
     int ncols = (mode == 0) ? N : K;
     if (mode == 0) {
@@ -1269,8 +1308,8 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
         bf16x8 wf[2];
         for (int t = 0; t < 2; ++t) wf[t] = w_frag(asg(B), N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-          bf16x8 a = lds_frag(c.P, LDP, c.wm * 128 + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+        for (int rt = 0; rt < RT; ++rt) {
+          bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
           for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
         }
@@ -1282,10 +1321,10 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
     for (int t = 0; t < 2; ++t) {
       int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
 #pragma unroll
-      for (int rt = 0; rt < 8; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int r = c.wm * 128 + rt * 16 + c.c16;
+          int r = c.wm * WROWS + rt * 16 + c.c16;
           if (f0 + i < ncols) Cout[(int64_t)r * ncols + f0 + i] = acc[t][rt][i];
         }
     }

@@ -2,7 +2,9 @@
 
 Tensors keep the reference's ``state_dict`` names, shapes and order (cVAE.py:140-206,
 1087-1116), so ``load_state_dict``/``state_dict`` interchange weights with the reference.
-Each tensor starts on a 16-byte boundary of the flat buffer (vector loads in the kernels).
+Inside the flat buffer every tensor starts on a 16-byte boundary and every weight matrix
+[N][K] is stored with its rows padded to a multiple of 8 floats (zeros), so each row is
+32-byte aligned: the kernels read weight fragments and sweep Adam with 16-byte accesses.
 """
 from __future__ import annotations
 
@@ -15,6 +17,7 @@ import torch
 from . import _lib
 
 ALIGN = 4   # floats
+ROW_PITCH = 8   # floats: weight-matrix rows are padded to this multiple (kpitch() in nmhip.hip)
 
 
 @dataclass
@@ -105,14 +108,17 @@ class ParamLayout:
         self.names: List[str] = []
         self.shapes: Dict[str, Tuple[int, ...]] = {}
         self.offsets: Dict[str, int] = {}
+        self.pitch: Dict[str, int] = {}
         off = 0
         for name, shape in tensor_table(spec):
             self.names.append(name)
             self.shapes[name] = shape
             self.offsets[name] = off
-            n = 1
-            for d in shape:
-                n *= d
+            if name.endswith(".weight") and len(shape) == 2:
+                self.pitch[name] = (shape[1] + ROW_PITCH - 1) // ROW_PITCH * ROW_PITCH
+                n = shape[0] * self.pitch[name]
+            else:
+                n = math.prod(shape)
             off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
         self.n_params = sum(math.prod(s) for s in self.shapes.values())
@@ -121,7 +127,12 @@ class ParamLayout:
         return math.prod(self.shapes[name])
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        """Strided view of one tensor inside the flat buffer (weights: padded row pitch)."""
         o = self.offsets[name]
+        if name in self.pitch:
+            n, k = self.shapes[name]
+            kp = self.pitch[name]
+            return flat[o:o + n * kp].view(n, kp)[:, :k]
         return flat[o:o + self.numel(name)].view(self.shapes[name])
 
     def unflatten(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -79,6 +79,12 @@ def test_param_layout_matches_reference_names():
             assert tuple(v.shape) == tuple(w[k].shape)
             assert (v == w[k]).all()
         assert all(o % 4 == 0 for o in lay.offsets.values())
+        assert all(v % 8 == 0 for v in lay.pitch.values())
+        # pad columns of every weight row stay zero
+        for k, kp in lay.pitch.items():
+            n, kk = lay.shapes[k]
+            o = lay.offsets[k]
+            assert (flat[o:o + n * kp].view(n, kp)[:, kk:] == 0).all()
     g = Golden("cfgA_T1w")
     assert nm.ParamLayout(nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim)).n_params == 118479
 

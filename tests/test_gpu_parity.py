@@ -51,6 +51,11 @@ def test_gemm_forms(mode):
         A = bf(torch.randn(M, N, generator=g)); B = bf(torch.randn(M, K, generator=g))
         ref = A.T @ B
         out = torch.zeros(N, K, device=DEV)
+    if mode in (0, 1):                    # weight operand in the flat-buffer format: rows padded to 8 floats
+        kp = (B.shape[1] + 7) // 8 * 8
+        Bp = torch.zeros(B.shape[0], kp)
+        Bp[:, :B.shape[1]] = B
+        B = Bp
     Ad, Bd = A.to(DEV).contiguous(), B.to(DEV).contiguous()
     _lib.check(lib.nm_test_gemm(mode, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), M, N, K, st))
     torch.cuda.synchronize()

@@ -10,7 +10,8 @@ from multi_modal_normative_modeling_amd import prep, workload, _lib
 
 PH = ["ENC_L0", "ENC_REST", "HEADS", "LATENT", "DEC_ZC", "DEC_HID", "OUT_GEMM", "OUT_DLV", "OUT_DGRAD", "OUT_WGRAD",
       "NLL_RED", "DEC_FINISH", "DEC_LOAD", "DEC_DGRAD", "DEC_WGRAD", "DEC_DELTA", "ALPHA", "ENCB_PREP",
-      "ENCB_HEADS_DGRAD", "ENCB_HEADS_WGRAD", "ENCB_LOAD", "ENCB_DGRAD", "ENCB_WGRAD", "ENCB_DELTA", "ENCB_L0_WGRAD"]
+      "ENCB_HEADS_DGRAD", "ENCB_HEADS_WGRAD", "ENCB_LOAD", "ENCB_DGRAD", "ENCB_WGRAD", "ENCB_DELTA", "ENCB_L0_WGRAD",
+      "X_LOADS", "X_MFMA", "X_EPI"]
 ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--procedure", default="SM-T1w_sMRI")
