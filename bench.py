@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=32)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
     ap.add_argument("--subjects", type=int, default=1280)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(affinity, 16))")
     args = ap.parse_args()
 
     T0 = time.perf_counter()
@@ -119,8 +120,17 @@ def main():
     bytes_per_launch = work["bytes"] * args.jobs * steps_per_launch          # algorithmic, SURVEY 8(d)
     flop_per_launch = work["flop"] * args.jobs * steps_per_launch
     hbm_gbs = bytes_per_launch / avg_launch_s / 1e9
+    # HBM traffic from the committed rocprofv3 PMC passes of this same command (profiles/): FETCH_SIZE and
+    # WRITE_SIZE in separate passes, KB -> bytes, FETCH doubled per the gfx950 correction.  null when the
+    # committed measurement is for a different workload.
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_hbm_traffic.json"
+    if pmc.exists():
+        rec = json.loads(pmc.read_text())
+        if rec.get("procedure") == args.procedure and rec.get("jobs") == args.jobs:
+            traffic = rec["hbm_bytes_per_job_step_corrected"] * args.jobs * steps_per_launch
     roofline = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(hbm_gbs / 8000.0, 5), "traffic": None,
+                "frac": round(hbm_gbs / 8000.0, 5), "traffic": traffic,
                 "kernel": "nm_step_kernel", "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                 "algorithmic_bytes_per_job_step": work["bytes"],
                 "mfma_bf16_tflops": round(flop_per_launch / avg_launch_s / 1e12, 3),
@@ -145,7 +155,10 @@ def main():
     if world == 1 and args.cpu_budget > 0:
         from oracle import cvae_ref as R
         from oracle.cpu_baseline import CpuStepper, time_cpu_steps
-        torch.set_num_threads(os.cpu_count() or 1)
+        # the GPU box hands one GPU a 16-core CPU share; os.cpu_count() reports the whole host
+        nthr = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
+        torch.set_num_threads(nthr)
+        log(f"cpu baseline on {nthr} threads")
         rs = R.Spec(list(spec.input_dims), list(spec.hidden), spec.latent, spec.c_dim)
         P = jobs[0].layout.init_reference_rule(42)
         stepper = CpuStepper(rs, P, jobs[0].combine)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# rocprofv3 --kernel-trace --stats of the bench command; summary lands in gpurun_out/prof_<tag>/
+set -e
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 "$@" > $OUT/bench.json 2> $OUT/bench.err || true
+find $OUT/raw -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+head -5 $OUT/kernel_stats.csv
+tail -1 $OUT/bench.json | cut -c1-400
+rm -rf $OUT/raw
