@@ -46,7 +46,8 @@ enum {
   NM_F_ADAM     = 2,   /* apply Adam inside the weight-gradient epilogues             */
   NM_F_GRADS    = 4,   /* store gradients to job.grads (parameter layout)             */
   NM_F_EXPORT   = 8,   /* store mu / logvar / z / loc / squared residual per row      */
-  NM_F_PROFILE  = 16   /* workgroup (0,0) accumulates per-phase shader-clock cycles   */
+  NM_F_PROFILE  = 16,  /* workgroup (0,0) accumulates per-phase shader-clock cycles   */
+  NM_F_ZGIVEN   = 32   /* job.eps holds the latent z itself: decode(z, c, m), cVAE.py:1135 */
 };
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the

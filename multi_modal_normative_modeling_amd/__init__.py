@@ -3,5 +3,7 @@ reference's own cVAE class surface).  See DESIGN.md."""
 from . import _lib
 from .layout import ModelSpec, ParamLayout
 from .engine import Table, Job, JobSet, adam_step
+from .api import cVAE, cVAE_multimodal, NormalLike
 
-__all__ = ["ModelSpec", "ParamLayout", "Table", "Job", "JobSet", "adam_step", "_lib"]
+__all__ = ["ModelSpec", "ParamLayout", "Table", "Job", "JobSet", "adam_step", "cVAE", "cVAE_multimodal", "NormalLike",
+           "_lib"]

@@ -23,6 +23,7 @@ NM_F_ADAM = 2
 NM_F_GRADS = 4
 NM_F_EXPORT = 8
 NM_F_PROFILE = 16
+NM_F_ZGIVEN = 32
 
 LIB_NAME = "libnmhip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME

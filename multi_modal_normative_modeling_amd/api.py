@@ -1,0 +1,352 @@
+"""The reference's own class surface (cVAE.py) on top of the HIP path.
+
+``cVAE`` (cVAE.py:391-562) and ``cVAE_multimodal`` (cVAE.py:1087-1211) keep their constructor
+signatures, method names, returned dict keys, attribute names (``optimizer1``, ``encoder_list``,
+``decoder_list``, ``alpha_m_list``) and ``state_dict`` keys, so the reference's train / test
+loops run unchanged:
+
+    fwd_rtn = model.forward_multimodal(xes, cs, combine)        # multimodal_kfold_train_...:193
+    loss = model.loss_function_multimodal(xes, fwd_rtn)         # :194
+    model.optimizer1.zero_grad(); loss['total'].backward(); model.optimizer1.step()   # :197-199
+
+Underneath, ``forward_multimodal`` is ONE launch of the fused step kernel (forward + ELBO +
+backward, gradients to a flat buffer), ``.backward()`` publishes those gradients and
+``optimizer1.step()`` is the flat Adam kernel.  The sweep (``sweep.py``) does not use this eager
+surface: it keeps whole training runs inside the persistent kernel.
+
+All arithmetic runs in libnmhip.so; there is no CPU fallback (NmError without a GPU).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import Job, JobSet, Table, adam_step, require_gpu
+from .layout import ModelSpec, ParamLayout
+
+
+class NormalLike:
+    """What callers use of ``torch.distributions.Normal`` (cVAE.py:206): loc / scale / mean / log_prob."""
+
+    def __init__(self, loc: torch.Tensor, scale: torch.Tensor):
+        self.loc, self.scale = loc, scale
+
+    @property
+    def mean(self):
+        return self.loc
+
+    def log_prob(self, x):
+        var = self.scale ** 2
+        return -((x - self.loc) ** 2) / (2 * var) - self.scale.log() - 0.9189385332046727
+
+
+class _Holder(nn.Module):
+    """Parameter holder reproducing one reference sub-module's parameter names."""
+
+    def __init__(self, **params):
+        super().__init__()
+        for k, v in params.items():
+            self.register_parameter(k, v)
+
+
+class _LossFn(torch.autograd.Function):
+    """Gives the loss scalars a ``.backward()`` that publishes the gradients the kernel produced."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, which, value):
+        ctx.model, ctx.which = model, which
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.model._publish_grads(ctx.which, g)
+        return None, None, None, None
+
+
+class _Adam:
+    """``optimizer1`` of the reference (torch.optim.Adam, lr = learning_rate, cVAE.py:1111-1116)."""
+
+    def __init__(self, model, lr):
+        self.model = model
+        self.param_groups = [{"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8}]
+        self.t = 0
+        self.lr = lr            # the reference's loop assigns this attribute; like there, it is inert
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.model._grads_ready = False
+
+    def step(self):
+        m = self.model
+        if not m._grads_ready:
+            raise RuntimeError("optimizer1.step() called without a preceding loss.backward()")
+        g = self.param_groups[0]
+        self.t += 1
+        adam_step(m._job.params, m._pending, m._job.adam_m, m._job.adam_v, self.t, lr=g["lr"], betas=g["betas"],
+                  eps=g["eps"])
+        m._job.t = self.t
+        m._job.touch()
+
+
+class _Base(nn.Module):
+    def _setup(self, spec: ModelSpec, learning_rate: float, kl_weight: float):
+        self.spec = spec
+        self.layout = ParamLayout(spec)
+        self._device = None
+        self._lr = learning_rate
+        self._kl_weight = kl_weight
+        self._flat = nn.Parameter(self.layout.flatten(self.layout.init_reference_rule(
+            int(torch.initial_seed() % (2 ** 31)))), requires_grad=False)
+        self._job: Optional[Job] = None
+        self._grads_ready = False
+        self._pending = None
+        self._last = None
+        self._anchor = torch.zeros(1, requires_grad=True)
+        self._build_tree()
+
+    # -- module tree with the reference's parameter names (views into the flat buffer) --------------
+    def _views(self):
+        return {k: v for k, v in self.layout.unflatten(self._flat.data).items()}
+
+    def _build_tree(self):
+        v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
+        s, L = self.spec, len(self.spec.hidden)
+
+        def enc(m):
+            p = s.enc_prefix(m)
+            layers = nn.ModuleList([_Holder(weight=v[f"{p}encoder_layers.{i}.weight"], bias=v[f"{p}encoder_layers.{i}.bias"])
+                                    for i in range(L)])
+            e = nn.Module()
+            e.encoder_layers = layers
+            e.enc_mean_layer = _Holder(weight=v[f"{p}enc_mean_layer.weight"], bias=v[f"{p}enc_mean_layer.bias"])
+            e.enc_logvar_layer = _Holder(weight=v[f"{p}enc_logvar_layer.weight"], bias=v[f"{p}enc_logvar_layer.bias"])
+            return e
+
+        def dec(m):
+            p = s.dec_prefix(m)
+            d = nn.Module()
+            d.register_parameter("logvar_out", v[f"{p}logvar_out"])
+            d.decoder_layers = nn.ModuleList([_Holder(weight=v[f"{p}decoder_layers.{i}.weight"],
+                                                      bias=v[f"{p}decoder_layers.{i}.bias"]) for i in range(L)])
+            d.decoder_mean_layer = _Holder(weight=v[f"{p}decoder_mean_layer.weight"], bias=v[f"{p}decoder_mean_layer.bias"])
+            return d
+
+        if s.kind == "single":
+            self.encoder, self.decoder = enc(0), dec(0)
+        else:
+            self.alpha_m_list = nn.ParameterList([v[f"alpha_m_list.{m}"] for m in range(s.M)])
+            self.encoder_list = nn.ModuleList([enc(m) for m in range(s.M)])
+            self.decoder_list = nn.ModuleList([dec(m) for m in range(s.M)])
+
+    def state_dict(self, *a, **k):
+        return {n: t.detach().cpu().clone() for n, t in self._views().items()}
+
+    def load_state_dict(self, state, strict: bool = True):
+        self._flat.data.copy_(self.layout.flatten(state, device=self._flat.device))
+        if self._job is not None:
+            self._job.params.copy_(self._flat.data)
+        return self
+
+    def to(self, device):
+        dev = require_gpu(device)
+        if self._device != dev:
+            self._flat.data = self._flat.data.to(dev)
+            self._build_tree()
+            self._device = dev
+            self._job = None
+        return self
+
+    # -- one launch: forward + ELBO + backward --------------------------------------------------------
+    def _ensure_device(self, like: torch.Tensor):
+        if self._device is None:
+            self.to(like.device if like.is_cuda else "cuda:0")
+
+    def _dev(self):
+        if self._device is None:
+            self.to("cuda:0")          # raises NmError when no MI355X is visible
+        return self._device
+
+    def _run(self, xes: Sequence[torch.Tensor], cs: Sequence[torch.Tensor], combine: str, flags: int, eps=None,
+             kl_w=None, ll_w=1.0):
+        self._ensure_device(xes[0])
+        tables = [Table(x, c, self._device) for x, c in zip(xes, cs)]
+        # reuse one Job (buffers) across calls; only the tables change
+        if self._job is None or self._job.combine != combine.lower() or self._job.tables[0].rows_alloc != tables[0].rows_alloc:
+            self._job = Job(self.spec, tables, combine=combine, state=self.state_dict(), lr=self._lr,
+                            kl_weight=self._kl_weight, loss_cap=1)
+            self._job.params = self._flat.data          # share storage with the module's parameters
+            self._job.enable_exports()
+        j = self._job
+        j.tables = tables
+        j.kl_weight = self._kl_weight if kl_w is None else kl_w
+        j.ll_weight = ll_w
+        B, Z = int(xes[0].shape[0]), self.spec.latent
+        if eps is None:
+            eps = torch.randn(B, Z, device=self._device)            # torch.randn_like(mu), cVAE.py:1132
+        j.set_eps(eps)
+        j.step = 0
+        j.touch()
+        JobSet([j])._launch(0, 1, 1, flags)
+        return j, B
+
+    def _publish_grads(self, which: str, g: torch.Tensor):
+        xes, cs, combine, eps = self._last
+        scale = float(g)
+        if which == "total":
+            pend = self._job.grads
+        else:       # d kl / d theta or d ll / d theta on their own: one more launch with the other term off
+            kl_w, ll_w = (self._kl_weight, 0.0) if which == "kl" else (0.0, -1.0)
+            j, _ = self._run(xes, cs, combine, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS, eps=eps, kl_w=kl_w, ll_w=ll_w)
+            pend = j.grads
+        self._pending = pend if scale == 1.0 else pend * scale
+        self._grads_ready = True
+        gv = self.layout.unflatten(self._pending)
+        for name, p in self._named_views():
+            p.grad = gv[name]
+
+    def _named_views(self):
+        out = []
+        for name, p in self.named_parameters():
+            if name != "_flat":
+                out.append((name, p))
+        return out
+
+    def reparameterise(self, mu, logvar):
+        return mu + torch.randn_like(mu) * torch.exp(0.5 * logvar)          # cVAE.py:418-421
+
+    def calc_kl(self, mu, logvar):
+        return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1).mean(0)
+
+    def calc_ll(self, x, x_recon):
+        return x_recon.log_prob(x).sum(1, keepdims=True).mean(0)
+
+    def sample_from_normal(self, normal):
+        return normal.loc
+
+    def _scale(self, m: int) -> torch.Tensor:
+        return self._views()[f"{self.spec.dec_prefix(m)}logvar_out"].exp().pow(0.5)
+
+    def _loss_dict(self, B):
+        row = self._job.loss_log[0]
+        mk = lambda which, val: _LossFn.apply(self._anchor, self, which, val)
+        return {"total": mk("total", row[_lib_loss("TOTAL")]), "kl": mk("kl", row[_lib_loss("KL")]),
+                "ll": mk("ll", row[_lib_loss("LL")].reshape(1))}
+
+
+def _lib_loss(which):
+    return {"TOTAL": 0, "KL": 1, "LL": 2}[which]
+
+
+class cVAE_multimodal(_Base):
+    """cVAE.py:1087-1211."""
+
+    def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
+                 non_linear=False):
+        super().__init__()
+        if modalities != len(input_dim_list):
+            raise ValueError("modalities must equal len(input_dim_list)")
+        self.input_dim_list = list(input_dim_list)
+        self.hidden_dim = list(hidden_dim) + [latent_dim]
+        self.latent_dim, self.c_dim, self.modalities, self.learning_rate = latent_dim, c_dim, modalities, learning_rate
+        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "multimodal"),
+                    learning_rate, kl_weight=float(modalities))
+        self.optimizer1 = _Adam(self, learning_rate)
+
+    def forward_multimodal(self, xes, cs, combine):
+        if combine.lower() not in _lib.NM_COMBINE:
+            raise ValueError("No such combination method")
+        self.zero_grad()
+        eps = torch.randn(int(xes[0].shape[0]), self.spec.latent, device=self._dev())
+        j, B = self._run(xes, cs, combine, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | _lib.NM_F_EXPORT, eps=eps)
+        self._last = (list(xes), list(cs), combine, eps)
+        x_recons = [NormalLike(j.out_loc[m][:B].clone(), self._scale(m)) for m in range(self.modalities)]
+        return {"x_recons": x_recons, "mu_multimodal": j.out_mu[:B].clone(), "logvar_multimodal": j.out_logvar[:B].clone()}
+
+    def loss_function_multimodal(self, xes, fwd_rtn):
+        return self._loss_dict(int(xes[0].shape[0]))
+
+    def encode(self, x, c, m):
+        """Encoder m alone: (mu, logvar) -- forward-only launch of a one-modality view."""
+        one = self._unimodal(m)
+        j, B = one._run([x], [c], "poe", _lib.NM_F_EXPORT, eps=torch.zeros(int(x.shape[0]), self.spec.latent,
+                                                                          device=self._dev()))
+        return j.out_mu[:B].clone(), j.out_logvar[:B].clone()
+
+    def decode(self, z, c, m):
+        """Decoder m alone on a given z (cVAE.py:1135)."""
+        one = self._unimodal(m)
+        x0 = torch.zeros(int(z.shape[0]), self.input_dim_list[m], device=self._dev())
+        j, B = one._run([x0], [c], "poe", _lib.NM_F_EXPORT | _lib.NM_F_ZGIVEN, eps=z)
+        return NormalLike(j.out_loc[0][:B].clone(), self._scale(m))
+
+    def _unimodal(self, m: int) -> "cVAE_multimodal":
+        self._dev()
+        cache = self.__dict__.setdefault("_uni", {})
+        if m not in cache:
+            u = cVAE_multimodal([self.input_dim_list[m]], self.spec.hidden, self.latent_dim, self.c_dim,
+                                self.learning_rate, 1, self.spec.non_linear)
+            u.to(self._device)
+            cache[m] = u
+        u = cache[m]
+        sd = self.state_dict()
+        u.load_state_dict({k: sd[k.replace("_list.0.", f"_list.{m}.")] for k in u.layout.names})
+        return u
+
+    def pred_recon(self, xes, c, DEVICE, combine):
+        """cVAE.py:1198-1208: DataFrames in, numpy reconstructions (joint latent, sampled z) out."""
+        xs = [torch.tensor(np.asarray(x.values if hasattr(x, "values") else x), dtype=torch.float32) for x in xes]
+        ct = torch.tensor(np.asarray(c), dtype=torch.long)
+        self._dev()
+        j, B = self._run(xs, [ct] * self.modalities, combine, _lib.NM_F_EXPORT)
+        return [j.out_loc[m][:B].cpu().numpy() for m in range(self.modalities)]
+
+    def reconstruction_deviation_multimodal(self, xes, x_preds):
+        return [np.sum((xes[m] - x_preds[m]) ** 2, axis=1) / xes[m].shape[1] for m in range(self.modalities)]
+
+
+class cVAE(_Base):
+    """cVAE.py:391-562 (encoder + decoder; the unused discriminator is not part of the hot path)."""
+
+    def __init__(self, input_dim, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=4, non_linear=False):
+        super().__init__()
+        self.input_dim, self.latent_dim, self.c_dim, self.learning_rate = input_dim, latent_dim, c_dim, learning_rate
+        self.hidden_dim = list(hidden_dim) + [latent_dim]
+        self.modalities = modalities
+        self._setup(ModelSpec([input_dim], list(hidden_dim), latent_dim, c_dim, non_linear, "single"), learning_rate, 1.0)
+        self.optimizer1 = _Adam(self, learning_rate)
+
+    def forward(self, x, c):
+        self.zero_grad()
+        eps = torch.randn(int(x.shape[0]), self.spec.latent, device=self._dev())
+        j, B = self._run([x], [c], "poe", _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | _lib.NM_F_EXPORT, eps=eps)
+        self._last = ([x], [c], "poe", eps)
+        return {"x_recon": NormalLike(j.out_loc[0][:B].clone(), self._scale(0)), "mu": j.out_mu[:B].clone(),
+                "logvar": j.out_logvar[:B].clone()}
+
+    def loss_function(self, x, fwd_rtn):
+        return self._loss_dict(int(x.shape[0]))
+
+    def encode(self, x, c):
+        j, B = self._run([x], [c], "poe", _lib.NM_F_EXPORT)
+        return j.out_mu[:B].clone(), j.out_logvar[:B].clone()
+
+    def decode(self, z, c):
+        x0 = torch.zeros(int(z.shape[0]), self.input_dim, device=self._dev())
+        j, B = self._run([x0], [c], "poe", _lib.NM_F_EXPORT | _lib.NM_F_ZGIVEN, eps=z)
+        return NormalLike(j.out_loc[0][:B].clone(), self._scale(0))
+
+    def pred_latent(self, x, c, DEVICE):
+        """cVAE.py:539-545."""
+        xt = torch.as_tensor(np.asarray(x.to_numpy() if hasattr(x, "to_numpy") else x), dtype=torch.float32)
+        mu, logvar = self.encode(xt, torch.as_tensor(np.asarray(c), dtype=torch.long))
+        return mu.cpu().numpy(), logvar.exp().cpu().numpy()
+
+    def pred_recon(self, x, c, DEVICE):
+        """cVAE.py:547-553: decodes mu (no draw)."""
+        xt = torch.as_tensor(np.asarray(x.to_numpy() if hasattr(x, "to_numpy") else x), dtype=torch.float32)
+        ct = torch.as_tensor(np.asarray(c), dtype=torch.long)
+        mu, _ = self.encode(xt, ct)
+        return self.decode(mu, ct).loc.cpu().numpy()

@@ -866,6 +866,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     float ep = J->eps ? asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + z]
                       : randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)z);
     float es = ep * expf(0.5f * f.lv);
+    if (c.flags & NM_F_ZGIVEN) { f.mu = ep; es = 0.f; }     // decode(z, c, m): the draw buffer holds z itself
     float zz = f.mu + es;
     ws_mu_j[r * Zs + z] = f.mu;
     ws_lv_j[r * Zs + z] = f.lv;

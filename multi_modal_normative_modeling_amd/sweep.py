@@ -1,0 +1,159 @@
+"""The k-fold x procedure sweep sharded over the GPUs of one node.
+
+Every (fold, procedure[, grid point]) cell is an independent model (the reference runs them as
+sequential loop iterations, multimodal_kfold_train_cvae_supervised.py:68,82), so the cells are
+dealt round-robin by descending cost to one process per GPU; each process trains its cells
+concurrently inside the persistent step kernel and writes its own ROI-wise CSVs.  The only
+collective is one all_gather of a small fp32 metric table at the end (RCCL on GPUs, gloo in the
+CPU tests) -- there is no data-path exchange.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import io, prep, workload
+from .engine import Job, JobSet, Table
+from .layout import ModelSpec
+
+N_METRICS = 8          # job_id, fold, proc_id, final_total_loss, auc, mean_dev_hc, mean_dev_dx, steps_per_s
+
+
+@dataclass(frozen=True)
+class Cell:
+    job_id: int
+    fold: int
+    proc_id: int
+    procedure: str
+    replica: int = 0
+
+    @property
+    def cost(self) -> float:
+        mods, _ = workload.procedure_modalities(self.procedure)
+        dims = [379 * 3 if m == prep.EARLY_FUSION else 379 for m in mods]
+        return workload.step_work(dims)["bytes"]
+
+
+def plan_cells(procedures: Sequence[str], n_folds: int, replicas: int = 1) -> List[Cell]:
+    cells, jid = [], 0
+    for r in range(replicas):
+        for p_id, proc in enumerate(procedures):
+            for k in range(n_folds):
+                cells.append(Cell(jid, k, p_id, proc, r))
+                jid += 1
+    return cells
+
+
+def assign(cells: Sequence[Cell], rank: int, world: int) -> List[Cell]:
+    """Static round-robin by descending cost; ties keep job_id order."""
+    order = sorted(cells, key=lambda c: (-c.cost, c.job_id))
+    return order[rank::world]
+
+
+def roc_auc(scores: np.ndarray, positive: np.ndarray) -> float:
+    """Rank-based ROC-AUC (ties get mid-ranks), = sklearn.metrics.roc_auc_score."""
+    scores = np.asarray(scores, dtype=np.float64)
+    positive = np.asarray(positive, dtype=bool)
+    n1, n0 = int(positive.sum()), int((~positive).sum())
+    if n1 == 0 or n0 == 0:
+        return float("nan")
+    order = np.argsort(scores, kind="mergesort")
+    ranks = np.empty(len(scores), dtype=np.float64)
+    s = scores[order]
+    i = 0
+    while i < len(s):
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    return float((ranks[positive].sum() - n1 * (n1 + 1) / 2.0) / (n1 * n0))
+
+
+def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Tensor:
+    """all_gather of the per-rank metric table [max_rows, N_METRICS] (unused rows = NaN)."""
+    import torch.distributed as dist
+    pad = torch.full((max_rows, N_METRICS), float("nan"), dtype=torch.float32, device=device or local.device)
+    pad[: local.shape[0]] = local.to(pad.device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return pad[~torch.isnan(pad[:, 0])].cpu()
+    bufs = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, pad)
+    allm = torch.cat(bufs).cpu()
+    allm = allm[~torch.isnan(allm[:, 0])]
+    return allm[torch.argsort(allm[:, 0])]
+
+
+def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int, epochs: int, device, out_dir=None,
+              lr: float = 1e-4, steps_per_launch: int = 64) -> torch.Tensor:
+    """Train the given cells concurrently, run the ROI-wise deviation pass, return the metric rows."""
+    if not cells:
+        return torch.empty(0, N_METRICS)
+    folds = prep.kfold_indices(len(cohort.iid), n_folds, 42)
+    jobs: List[Job] = []
+    for c in cells:
+        mods, combine = workload.procedure_modalities(c.procedure)
+        xs, cov = prep.fold_train_tables(cohort, mods, folds[c.fold][0])
+        tables = [Table(x, cov, device) for x in xs]
+        spec = ModelSpec([t.D for t in tables], list(workload.HIDDEN), workload.LATENT, workload.C_DIM)
+        jobs.append(Job(spec, tables, combine=combine, lr=lr, seed=1000 * c.fold + c.job_id, init_seed=42 + c.job_id,
+                        loss_cap=max(8, epochs * 8)))
+    # cells of different shapes take different time per step: group by shape so a launch is balanced
+    groups: Dict[tuple, List[int]] = {}
+    for i, j in enumerate(jobs):
+        groups.setdefault(tuple(j.spec.input_dims), []).append(i)
+    t0 = time.perf_counter()
+    total_steps = 0
+    for idxs in groups.values():
+        js = JobSet([jobs[i] for i in idxs])
+        n = epochs * jobs[idxs[0]].batches_per_epoch
+        done = 0
+        while done < n:
+            k = min(steps_per_launch, n - done)
+            js.train(k)
+            done += k
+        total_steps += n * len(idxs)
+    torch.cuda.synchronize(device)
+    sps = total_steps / max(time.perf_counter() - t0, 1e-9)
+    rows = []
+    for c, j in zip(cells, jobs):
+        mods, _ = workload.procedure_modalities(c.procedure)
+        last = (j.step - 1) % j.loss_cap
+        final_loss = float(j.loss_log[last, 0])
+        per_subject = []
+        for m, name in enumerate(mods):
+            dev, iids = deviation_roiwise(j, m, cohort, name, device)
+            per_subject.append(dev.mean(axis=1))
+            if out_dir is not None:
+                io.write_roiwise_csv(out_dir, c.fold, name if c.replica == 0 else f"{name}_r{c.replica}", iids, dev)
+        score = np.mean(per_subject, axis=0)
+        dx = cohort.dia == 0
+        rows.append([c.job_id, c.fold, c.proc_id, final_loss, roc_auc(score, dx), float(score[~dx].mean()),
+                     float(score[dx].mean()), sps])
+    return torch.tensor(rows, dtype=torch.float32)
+
+
+def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str, device):
+    """ROI-wise deviation of ALL subjects through modality m's own encoder/decoder with a sampled z
+    and a scaler re-fit on all subjects -- exactly the pass of
+    multimodal_kfold_train_cvae_supervised_regression.py:163-192."""
+    src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
+    center, scale = prep.robust_scaler_fit(src.astype(np.float32))
+    x = prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32)
+    c = prep.one_hot_covariates(cohort.age, cohort.gender)
+    spec1 = ModelSpec([job.spec.input_dims[m]], list(job.spec.hidden), job.spec.latent, job.spec.c_dim)
+    sd = job.state_dict()
+    from .layout import ParamLayout
+    st = {k: sd[k.replace("_list.0.", f"_list.{m}.")] for k in ParamLayout(spec1).names}
+    table = Table(x, c, device)
+    one = Job(spec1, [table], combine="poe", state=st, seed=job.seed + 7919 * (m + 1), n_tiles_ws=table.n_tiles)
+    one.enable_exports(loc=False, sqerr=True, rowdev=False, latent=False)
+    JobSet([one]).forward()
+    torch.cuda.synchronize(device)
+    return one.out_sqerr[0][: table.N].cpu().numpy(), cohort.iid

@@ -1,0 +1,99 @@
+"""Host logic of the sweep (CPU): cell planning / sharding, the rank-based AUC, the CSV layouts,
+and the ONE collective of the path -- the final metric all_gather -- with gloo, world_size 2."""
+import os
+import tempfile
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from sklearn.metrics import roc_auc_score
+
+from multi_modal_normative_modeling_amd import io, prep, sweep
+from tests.golden_util import GOLDEN
+
+
+def test_cells_cover_the_grid_once_and_balance():
+    procs = ["SM-T1w_sMRI", "SM-T2w_sMRI", "SM-fMRI", "SM-" + prep.EARLY_FUSION]
+    cells = sweep.plan_cells(procs, 5)
+    assert len(cells) == 20
+    for world in (1, 2, 4, 8):
+        shards = [sweep.assign(cells, r, world) for r in range(world)]
+        ids = sorted(c.job_id for s in shards for c in s)
+        assert ids == list(range(20))                                   # every cell exactly once
+        sizes = [len(s) for s in shards]
+        assert max(sizes) - min(sizes) <= 1
+    # costliest cells (early fusion, 1137 ROI) are dealt first
+    assert sweep.assign(cells, 0, 8)[0].procedure.endswith(prep.EARLY_FUSION)
+
+
+def test_roc_auc_matches_sklearn_with_ties():
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 20, size=300).astype(float)
+    y = rng.random(300) < 0.3
+    assert abs(sweep.roc_auc(s, y) - roc_auc_score(y, s)) < 1e-12
+    assert np.isnan(sweep.roc_auc(s, np.zeros(300, dtype=bool)))
+
+
+def test_roiwise_csv_layout_matches_reference_file():
+    z = np.load(GOLDEN / "csv_layouts.npz", allow_pickle=False)
+    header = [str(h) for h in z["roiwise_header"]]
+    iids = z["roiwise_iid"]
+    vals = z["roiwise_row0_vals"]
+    dev = np.tile(vals, (len(iids), 1)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        p = io.write_roiwise_csv(d, 0, "T1w_sMRI", iids, dev)
+        assert p.name == "deviation_fold_0_T1w_sMRI_roiwise.csv"       # ..._regression.py:192
+        with open(p) as f:
+            assert f.readline().strip().split(",") == header           # IID, ROI_0 .. ROI_{D-1}
+            assert f.readline().strip() == str(z["roiwise_row0_text"])  # same float32 text as the reference's file
+        back = pd.read_csv(p)
+        assert (back["IID"].to_numpy() == iids).all()                   # row order = table order, bit-exact ids
+
+
+def test_test_script_csv_kinds():
+    cov = pd.DataFrame({"participant_id": [1, 2], "DIA": [1, 0], "AGE": [30, 31], "PTGENDER": [0, 1]})
+    x = np.array([[1.0, 2.0, 3.0], [0.0, 1.0, 0.5]])
+    xh = np.array([[0.5, 2.0, 2.0], [0.0, 0.0, 0.5]])
+    with tempfile.TemporaryDirectory() as d:
+        paths = io.write_test_csvs(d, "av45", cov, ["a", "b", "c"], x, xh)
+        err = pd.read_csv(paths["reconstruction_error"])
+        assert list(err.columns) == io.META_COLS + ["Reconstruction error"]
+        np.testing.assert_allclose(err["Reconstruction error"], ((x - xh) ** 2).sum(1) / 3)
+        fi = pd.read_csv(paths["deviation_as_feature_importance"])
+        assert list(fi.columns) == io.META_COLS + ["1", "2", "3"]
+        roi = pd.read_csv(paths["reconstruction_error_roi"])
+        np.testing.assert_allclose(roi[["a", "b", "c"]].to_numpy(), (x - xh) ** 2)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cells = sweep.plan_cells(["SM-T1w_sMRI", "SM-fMRI", "SE-gPoE"], 3)
+    mine = sweep.assign(cells, rank, world)
+    # stand-in for the GPU work: each rank fills the metric rows of ITS cells
+    local = torch.tensor([[c.job_id, c.fold, c.proc_id, 100.0 + c.job_id, 0.5, 1.0, 2.0, 10.0 * (rank + 1)] for c in mine],
+                         dtype=torch.float32)
+    allm = sweep.gather_metrics(local, max_rows=math_ceil(len(cells), world))
+    if rank == 0:
+        torch.save(allm, out)
+    dist.destroy_process_group()
+
+
+def math_ceil(a, b):
+    return (a + b - 1) // b
+
+
+def test_metric_gather_gloo_world2():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "m.pt")
+        port = 29500 + (os.getpid() % 500)
+        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        allm = torch.load(out, weights_only=True)
+    assert allm.shape == (9, sweep.N_METRICS)
+    assert allm[:, 0].tolist() == list(range(9))                        # every cell once, ordered by job id
+    assert torch.allclose(allm[:, 3], 100.0 + allm[:, 0])
+    assert set(allm[:, 7].tolist()) == {10.0, 20.0}                     # rows really came from both ranks
