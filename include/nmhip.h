@@ -47,7 +47,8 @@ enum {
   NM_F_GRADS    = 4,   /* store gradients to job.grads (parameter layout)             */
   NM_F_EXPORT   = 8,   /* store mu / logvar / z / loc / squared residual per row      */
   NM_F_PROFILE  = 16,  /* workgroup (0,0) accumulates per-phase shader-clock cycles   */
-  NM_F_ZGIVEN   = 32   /* job.eps holds the latent z itself: decode(z, c, m), cVAE.py:1135 */
+  NM_F_ZGIVEN   = 32,  /* job.eps holds the latent z itself: decode(z, c, m), cVAE.py:1135 */
+  NM_F_TRACE    = 64   /* workgroup (0,0): per-wave interval timers between in-kernel stamps */
 };
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the
@@ -156,6 +157,9 @@ int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int ste
 
 /* NM_F_PROFILE read-out: 32 per-phase cycle counters of workgroup (0,0); reset != 0 clears them. */
 int nm_prof_read(unsigned long long* out32, int reset);
+
+/* NM_F_TRACE read-out: [8 waves][64 tags] interval cycles of workgroup (0,0); reset != 0 clears them. */
+int nm_trace_read(unsigned long long* out512, int reset);
 
 const char* nm_status_string(int status);
 int nm_version(void);

@@ -24,6 +24,7 @@ NM_F_GRADS = 4
 NM_F_EXPORT = 8
 NM_F_PROFILE = 16
 NM_F_ZGIVEN = 32
+NM_F_TRACE = 64
 
 LIB_NAME = "libnmhip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
@@ -94,6 +95,7 @@ def load():
     lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     lib.nm_prof_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
+    lib.nm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
     sj, sm = i64(0), i64(0)
     lib.nm_abi_sizes(C.byref(sj), C.byref(sm))
     if sj.value != C.sizeof(NmJob) or sm.value != C.sizeof(NmModality):
@@ -106,7 +108,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read",
 ]
 
 

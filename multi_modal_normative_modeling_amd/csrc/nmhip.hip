@@ -63,6 +63,9 @@ typedef const GAS __bf16* gcbf16;
 
 // Phase timers (NM_F_PROFILE): shader-clock cycles of workgroup (0,0), thread 0, accumulated per phase.
 __device__ unsigned long long nm_prof_cycles[32];
+// Per-wave interval timers (NM_F_TRACE): cycles between consecutive stamps of each wave of workgroup (0,0),
+// attributed to the tag of the later stamp.
+__device__ unsigned long long nm_trace_cycles[8][64];
 
 struct Ctx {
   unsigned long long t_last;
@@ -73,6 +76,7 @@ struct Ctx {
   float* red;        // [64] reduction scratch
   float* colacc;     // [128] per-column accumulators
   float* rowacc;     // [256] per-row accumulators
+  unsigned long long* tlast;   // [8] last stamp per wave (NM_F_TRACE)
   int tid, lane, wave, wm, wn, g, c16;
   int row0;          // first table row of this tile
   int nrows;         // valid rows in this tile (<= 256)
@@ -117,6 +121,14 @@ enum { PH_ENC_L0 = 0, PH_ENC_REST, PH_HEADS, PH_LATENT, PH_DEC_ZC, PH_DEC_HID, P
        PH_OUT_WGRAD, PH_NLL_RED, PH_DEC_FINISH, PH_DEC_LOAD, PH_DEC_DGRAD, PH_DEC_WGRAD, PH_DEC_DELTA, PH_ALPHA,
        PH_ENCB_PREP, PH_ENCB_HEADS_DGRAD, PH_ENCB_HEADS_WGRAD, PH_ENCB_LOAD, PH_ENCB_DGRAD, PH_ENCB_WGRAD,
        PH_ENCB_DELTA, PH_ENCB_L0_WGRAD, PH_X_LOADS, PH_X_MFMA, PH_X_EPI, PH_COUNT };
+__device__ __forceinline__ void tr(const Ctx& c, int tag) {
+  if ((c.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) {
+    unsigned long long t = clock64();
+    int w = threadIdx.x >> 6;
+    nm_trace_cycles[w][tag] += t - c.tlast[w];
+    c.tlast[w] = t;
+  }
+}
 __device__ __forceinline__ void prof(Ctx& c, int phase) {
   if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     unsigned long long t = clock64();
@@ -147,6 +159,15 @@ __device__ __forceinline__ void relaunder(Ctx& c) {
 template <class T>
 __device__ __forceinline__ GAS T* asg(T* p) {
   return (GAS T*)p;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every global
+// load/store in flight (weight / p-m-v / x prefetches, activation saves) would be waited for at every
+// phase boundary.  Used wherever the barrier protects P / Q / the slab; hand-offs through global
+// memory between threads keep __syncthreads().
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 }
 
 __device__ __forceinline__ float lrelu(float v, bool nl) { return (nl && v < 0.f) ? v * SLOPE : v; }
@@ -266,8 +287,10 @@ __device__ __forceinline__ AdamK adam_consts(const Ctx& c) {
 __device__ __forceinline__ void adam1(const AdamK& a, float g, float& p, float& m, float& v) {
   m = m + (g - m) * (1.0f - a.b1);                    // exp_avg.lerp_(grad, 1 - beta1)
   v = v * a.b2 + (1.0f - a.b2) * g * g;               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-  float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
-  p = p - a.step_size * (m / denom);
+  // v_sqrt_f32 / v_rcp_f32 (1 ulp): the update is ~lr * O(1), so the difference to the correctly rounded
+  // sequence is ~1e-11 absolute, far below fp32 resolution of the parameters
+  float denom = __builtin_amdgcn_sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+  p = p - a.step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 // scalar gradient sink (a handful of elements per step: alpha, d logvar_out)
@@ -408,6 +431,7 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       wf[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+  tr(c, 0);
   f32x4 acc[2][RT];
   bias_acc(c, acc, b, N, 0);
 #pragma unroll
@@ -421,10 +445,15 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
       }
     }
   }
-  __syncthreads();                       // every wave has finished reading P
+  tr(c, 1);
+  lds_barrier();                       // every wave has finished reading P
+  tr(c, 2);
   act_to_P(c, acc, N, ntn, act);
-  __syncthreads();
+  tr(c, 3);
+  lds_barrier();
+  tr(c, 4);
   if (save) store_act(c, save, c.P, wpad(N));
+  tr(c, 5);
 }
 
 // ---- GEMM phase: first encoder layer, x streamed through Q in 64-column chunks ----------------
@@ -444,9 +473,12 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int t = 0; t < 2; ++t) wf[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+  tr(c, 6);
   for (int kc = 0; kc < nch; ++kc) {
     xchunk_store(c, st, c.Q);
-    __syncthreads();
+    tr(c, 7);
+    lds_barrier();
+    tr(c, 8);
     bf16x8 wn[2][2];
     if (kc + 1 < nch) {                   // next chunk's inputs and weights fly during this chunk's MFMAs
       xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
@@ -456,6 +488,7 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
         for (int t = 0; t < 2; ++t)
           wn[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (kc + 1) * XCH + ks * 32 + 8 * c.g);
     }
+    tr(c, 9);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (kc * XCH + ks * 32 < Kx) {
@@ -473,11 +506,14 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
 #pragma unroll
         for (int t = 0; t < 2; ++t) wf[ks][t] = wn[ks][t];
     }
-    __syncthreads();
+    tr(c, 10);
+    lds_barrier();
+    tr(c, 11);
   }
   act_to_P(c, acc, N, ntn, act);
-  __syncthreads();
+  lds_barrier();
   if (save) store_act(c, save, c.P, wpad(N));
+  tr(c, 12);
 }
 
 // ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
@@ -523,7 +559,9 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, g
       *(GAS f32x4*)(lv_out + r * Zs + f0) = al[rt];
     }
   }
+  tr(c, 13);
   __syncthreads();
+  tr(c, 14);
 }
 
 // ---- dgrad: acc[k][r] += sum_n A[r][n] W[n][k]  (contraction over the columns of A) ------------
@@ -533,6 +571,7 @@ __device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][RT], co
                                           int nsteps, int n_base) {
   Ctx c = cc;
   relaunder(c);
+  tr(c, 33);
   for (int s0 = 0; s0 < nsteps; s0 += 2) {
     bf16x8 wf[2][2];
 #pragma unroll
@@ -651,43 +690,54 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
         vv[j] = *(const GAS f32x4*)(asg(J->adam_v) + pidx[j]);
       }
     }
-    // ---- tiles -> slab (one 16x16 tile per wave and turn) ----
-    for (int u = c.wave; u < nts * nkt; u += NWAVES) {
-      const int nt = u / nkt, kt = u - nt * nkt;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const int ncol = a_col0 + n0 + nt * 16;
+    tr(c, 26);
+    // ---- tiles -> slab: a unit is one k tile x two n tiles (the k-side fragment is shared) ----
+    const int npairs = (nts + 1) / 2;
+    for (int u = c.wave; u < nkt * npairs; u += NWAVES) {
+      const int kt = u % nkt, np = u / nkt;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const int ncol0 = a_col0 + n0 + np * 32;
       if (SCALAR_TR) {
         for (int rs = 0; rs < ROWS / 32; ++rs) {
-          bf16x8 bn = lds_frag_tr_scalar(A, lda, rs * 32, ncol, c.lane);
           bf16x8 akf = lds_frag_tr_scalar(B, ldb, rs * 32, kt * 16, c.lane);
-          acc = mfma(akf, bn, acc);
+          acc0 = mfma(akf, lds_frag_tr_scalar(A, lda, rs * 32, ncol0, c.lane), acc0);
+          acc1 = mfma(akf, lds_frag_tr_scalar(A, lda, rs * 32, ncol0 + 16, c.lane), acc1);
         }
       } else {
-        unsigned na = tr_addr(A, lda, 0, ncol, c.lane);
+        unsigned na = tr_addr(A, lda, 0, ncol0, c.lane);
         unsigned ka = tr_addr(B, ldb, 0, kt * 16, c.lane);
         const unsigned n_step = 32u * lda * 2u, k_step = 32u * ldb * 2u;
         const unsigned n4 = 4u * lda * 2u, k4 = 4u * ldb * 2u;
 #pragma unroll 2
         for (int rs = 0; rs < ROWS / 32; rs += 2) {
-          // two row steps per wait: 8 transposing reads in flight
-          bf16x4 n0v, n1v, k0v, k1v, n2v, n3v, k2v, k3v;
+          // two row steps per wait: 12 transposing reads in flight (k side once, two n tiles)
+          bf16x4 k0v, k1v, k2v, k3v, a0, a1, a2, a3, b0, b1, b2, b3;
           unsigned na1 = na + n4, ka1 = ka + k4, na2 = na + n_step, ka2 = ka + k_step;
           unsigned na3 = na2 + n4, ka3 = ka2 + k4;
-          NM_TR_READ(n0v, na, 0);  NM_TR_READ(n1v, na1, 0);
           NM_TR_READ(k0v, ka, 0);  NM_TR_READ(k1v, ka1, 0);
-          NM_TR_READ(n2v, na2, 0); NM_TR_READ(n3v, na3, 0);
+          NM_TR_READ(a0, na, 0);   NM_TR_READ(a1, na1, 0);
+          NM_TR_READ(b0, na, 32);  NM_TR_READ(b1, na1, 32);
           NM_TR_READ(k2v, ka2, 0); NM_TR_READ(k3v, ka3, 0);
+          NM_TR_READ(a2, na2, 0);  NM_TR_READ(a3, na3, 0);
+          NM_TR_READ(b2, na2, 32); NM_TR_READ(b3, na3, 32);
           asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(n0v), "+v"(n1v), "+v"(k0v), "+v"(k1v), "+v"(n2v), "+v"(n3v), "+v"(k2v), "+v"(k3v));
-          acc = mfma(join4(k0v, k1v), join4(n0v, n1v), acc);
-          acc = mfma(join4(k2v, k3v), join4(n2v, n3v), acc);
+                       : "+v"(k0v), "+v"(k1v), "+v"(k2v), "+v"(k3v), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0),
+                         "+v"(b1), "+v"(b2), "+v"(b3));
+          bf16x8 kf0 = join4(k0v, k1v), kf1 = join4(k2v, k3v);
+          acc0 = mfma(kf0, join4(a0, a1), acc0);
+          acc1 = mfma(kf0, join4(b0, b1), acc1);
+          acc0 = mfma(kf1, join4(a2, a3), acc0);
+          acc1 = mfma(kf1, join4(b2, b3), acc1);
           na += 2 * n_step; ka += 2 * k_step;
         }
       }
-      // lane holds dW[n = nt*16 + c16][kk = kt*16 + 4g .. +3]
-      *reinterpret_cast<f32x4*>(c.stage + (nt * 16 + c.c16) * SP + kt * 16 + 4 * c.g) = acc;
+      // lane holds dW[n = (2 np + h)*16 + c16][kk = kt*16 + 4g .. +3]
+      *reinterpret_cast<f32x4*>(c.stage + (np * 32 + c.c16) * SP + kt * 16 + 4 * c.g) = acc0;
+      if (np * 2 + 1 < nts) *reinterpret_cast<f32x4*>(c.stage + (np * 32 + 16 + c.c16) * SP + kt * 16 + 4 * c.g) = acc1;
     }
-    __syncthreads();
+    tr(c, 27);
+    lds_barrier();
+    tr(c, 28);
     // ---- Adam on this thread's group; bias column by the first nr threads ----
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -707,7 +757,9 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
       }
     }
     if (has_bias && c.tid < nr) apply_grad(c, b_off + n0 + c.tid, c.stage[c.tid * SP + (K - k_base)]);
-    __syncthreads();
+    tr(c, 29);
+    lds_barrier();
+    tr(c, 30);
   }
 }
 
@@ -882,7 +934,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       }
     }
   }
+  tr(c, 15);
   float kl = block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
+  tr(c, 22);
   prof(c, PH_LATENT);
 
   // ================= decoders (forward, NLL, and the whole decoder backward) =================
@@ -893,8 +947,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const int D = md.D;
     const int Kd0 = Z + C;
     build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
-    __syncthreads();
+    tr(c, 23);
+    lds_barrier();
     if (bwd) store_act(c, ws_zc, c.P, wpad(Kd0));
+    tr(c, 24);
     prof(c, PH_DEC_ZC);
     // --- hidden decoder layers ---
     for (int d = 0; d < L; ++d) {
@@ -920,8 +976,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       relaunder(c);
       const int d0 = ch * PW;
       const int valid = min(PW, D - d0);
+      tr(c, 16);
       if (c.tid < PW) c.colacc[c.tid] = 0.f;
-      __syncthreads();
+      lds_barrier();
+      tr(c, 17);
       // x_hat chunk: acc[d][r]
       {
         const int ksteps = wpad(Hl) / 32;
@@ -948,6 +1006,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
         }
         prof(c, PH_X_LOADS);
+        tr(c, 18);
         f32x4 acc[2][RT];
         bias_acc(c, acc, bo, D, d0);
 #pragma unroll
@@ -962,14 +1021,22 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           }
         }
         prof(c, PH_X_MFMA);
+        tr(c, 19);
         // epilogue: residual, NLL, d logvar_out, delta chunk -> Q.  Lane: 4 consecutive ROI of one row.
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int dl0 = (c.wn + 4 * t) * 16 + 4 * c.g;       // first of the lane's 4 columns inside the chunk
           const int dg0 = d0 + dl0;
-          float inv[4], colsum[4];
+          // per column: q = sum_r diff^2 (valid rows only).  Then  NLL = sum_d [0.5 e^{-s} q + n (0.5 s + log sqrt(2 pi))]
+          // and d(-LL)/d s_d = (0.5 n - 0.5 e^{-s} q) / B: one masked square-accumulate per element instead of
+          // evaluating both sums element by element.
+          float inv[4], colq[4], coef[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { inv[i] = expf(-sv[t][i]); colsum[i] = 0.f; }
+          for (int i = 0; i < 4; ++i) {
+            inv[i] = expf(-sv[t][i]);
+            colq[i] = 0.f;
+            coef[i] = (dg0 + i < D) ? J->ll_weight * inv[i] * c.inv_b : 0.f;     // d total / d x_hat = coef * diff
+          }
           f32x4 xcur[RT];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) xcur[rt] = xin[rt];
@@ -979,21 +1046,28 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             for (int rt = 0; rt < RT; ++rt)
               xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
           }
+          int nvalid = 0;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const int r = c.wm * WROWS + rt * 16 + c.c16;
             const bool rv = r < c.nrows;
+            nvalid += rv ? 1 : 0;
             bf16x4 pk;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const bool ok = rv && (dg0 + i < D);
-              const float diff = acc[t][rt][i] - xcur[rt][i];
-              const float q = diff * diff * inv[i];
-              nll_part += ok ? (0.5f * q + 0.5f * sv[t][i] + LOG_SQRT_2PI) : 0.f;
-              colsum[i] += ok ? (0.5f - 0.5f * q) : 0.f;
-              pk[i] = (__bf16)(ok ? J->ll_weight * diff * inv[i] * c.inv_b : 0.f);
+              const float diff = rv ? acc[t][rt][i] - xcur[rt][i] : 0.f;
+              colq[i] = fmaf(diff, diff, colq[i]);
+              pk[i] = (__bf16)(diff * coef[i]);
             }
             if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
+          }
+          float colsum[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool dv = dg0 + i < D;
+            const float hq = 0.5f * inv[i] * colq[i];
+            nll_part += dv ? hq + (float)nvalid * (0.5f * sv[t][i] + LOG_SQRT_2PI) : 0.f;
+            colsum[i] = dv ? 0.5f * (float)nvalid - hq : 0.f;
           }
           if (exportf) {
 #pragma unroll
@@ -1025,15 +1099,19 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         }
       }
       prof(c, PH_X_EPI);
+      tr(c, 20);
       if (!bwd) continue;
-      __syncthreads();
+      lds_barrier();
+      tr(c, 21);
       prof(c, PH_OUT_GEMM);
       // d logvar_out for this chunk
       if (c.tid < valid) apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b);
       prof(c, PH_OUT_DLV);
       // dgrad into the last hidden activation: accg[k][r] += sum_d Q[r][d] Wo[d0 + d][k]
       dgrad_acc(c, accg, c.Q, Wo, D, Hl, rup(valid, 32) / 32, d0);
-      __syncthreads();                              // all reads of the old Wo are done
+      tr(c, 34);
+      lds_barrier();                              // all reads of the old Wo are done
+      tr(c, 35);
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
       wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, rup(Hl + 1, 16),
@@ -1047,28 +1125,36 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_LL_M + m] = ll_this;
     prof(c, PH_NLL_RED);
     if (exportf && md.out_rowdev) {
-      __syncthreads();
+      lds_barrier();
       for (int r = c.tid; r < c.nrows; r += WG) asg(md.out_rowdev)[c.row0 + r] = c.rowacc[r] / (float)D;
     }
     if (!bwd) { __syncthreads(); continue; }
 
     // --- decoder hidden layers, backward ---
     // state: P = activation g_{L-1}, accg = pre-mask delta of g_{L-1}
+    tr(c, 43);
     finish_delta(c, accg, c.P, Hl, nl);             // mask source is P itself (same element)
-    __syncthreads();
+    tr(c, 44);
+    lds_barrier();
+    tr(c, 45);
     prof(c, PH_DEC_FINISH);
     for (int d = L - 1; d >= 0; --d) {
       relaunder(c);
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
       // Q <- input activation of decoder layer d
+      tr(c, 31);
       load_act(c, c.Q, d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ROWS * PW, wpad(Kin));
-      __syncthreads();
+      tr(c, 32);
+      lds_barrier();
+      tr(c, 36);
       prof(c, PH_DEC_LOAD);
       f32x4 acc[2][RT];
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.dec_w[d], Nout, Kin, wpad(Nout) / 32, 0);
-      __syncthreads();                              // old weights fully read
+      tr(c, 34);
+      lds_barrier();                              // old weights fully read
+      tr(c, 35);
       prof(c, PH_DEC_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.dec_w[d], md.dec_b[d]);
       prof(c, PH_DEC_WGRAD);
@@ -1145,50 +1231,60 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const int Hh = J->H[L - 1];
     const int whp = rup(2 * Zs, 32);
     const float rwh = 1.0f / (float)whp;
-    // P <- [d mu_m | d logvar_m], Q <- last hidden activation
+    // P <- [d mu_m | 0 | d logvar_m | 0] (pad columns first, then one fusion backward per (row, z)),
+    // Q <- last hidden activation
+    {
+      const int npad = whp - 2 * Z;
+      const float rnp = npad > 0 ? 1.0f / (float)npad : 0.f;
+      for (int e = c.tid; e < ROWS * npad; e += WG) {
+        int r = idiv(e, npad, rnp), j = e - r * npad;
+        int k = (j < Zs - Z) ? Z + j : Zs + Z + (j - (Zs - Z));
+        c.P[r * LDP + k] = (__bf16)0.0f;
+      }
 #pragma unroll 2
-    for (int e = c.tid; e < ROWS * whp; e += WG) {
-      int r = idiv(e, whp, rwh), k = e - r * whp;
-      int z = (k < Zs) ? k : k - Zs;
-      float v = 0.f;
-      if (z < Z && k < 2 * Zs && r < c.nrows) {
+      for (int e = c.tid; e < ROWS * Z; e += WG) {
+        int r = idiv(e, Z, rZ), z = e - r * Z;
         Lat Lt;
         load_lat(Lt, r, z);
         float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
         float dmu_j = dz + klw * mj;
         float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
         FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
-        v = (k < Zs) ? pick(G.dmu, m) : pick(G.dlv, m);
+        const bool rv = r < c.nrows;
+        c.P[r * LDP + z] = (__bf16)(rv ? pick(G.dmu, m) : 0.f);
+        c.P[r * LDP + Zs + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
       }
-      c.P[r * LDP + k] = (__bf16)v;
     }
+    tr(c, 37);
     load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW, wpad(Hh));
-    __syncthreads();
+    tr(c, 38);
+    lds_barrier();
+    tr(c, 39);
     prof(c, PH_ENCB_PREP);
     f32x4 acc[2][RT];
     zero_acc(acc);
     dgrad_heads(c, acc, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
-    __syncthreads();
+    lds_barrier();
     prof(c, PH_ENCB_HEADS_DGRAD);
     wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.mu_w, md.mu_b);
     wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.lv_w, md.lv_b);
     prof(c, PH_ENCB_HEADS_WGRAD);
     finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
-    __syncthreads();
+    lds_barrier();
     prof(c, PH_ENCB_DELTA);
     for (int e = L - 1; e >= 1; --e) {
       int Kin = J->H[e - 1], Nout = J->H[e];
       load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW, wpad(Kin));
-      __syncthreads();
+      lds_barrier();
       prof(c, PH_ENCB_LOAD);
       zero_acc(acc);
       dgrad_acc(c, acc, c.P, prm + md.enc_w[e], Nout, Kin, wpad(Nout) / 32, 0);
-      __syncthreads();
+      lds_barrier();
       prof(c, PH_ENCB_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.enc_w[e], md.enc_b[e]);
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
-      __syncthreads();
+      lds_barrier();
       prof(c, PH_ENCB_DELTA);
     }
     // first encoder layer: dW[n][k] = sum_r P[r][n] xc[r][k], x streamed through Q
@@ -1198,8 +1294,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       XStage st;
       xchunk_load(c, st, asg(md.xb), Kx, 0);
       for (int kc = 0; kc < nch; ++kc) {
+        tr(c, 40);
         xchunk_store(c, st, c.Q);
-        __syncthreads();
+        tr(c, 41);
+        lds_barrier();
+        tr(c, 42);
         if (kc + 1 < nch) xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
         int cols = min(XCH, Kx - kc * XCH);
         wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDX, N0, K0, kc * XCH, cols, md.enc_w[0], md.enc_b[0]);
@@ -1210,7 +1309,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 }
 
 // ----------------------------------------------------------------------------------------------
-constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (STAGE_FLOATS + 64 + 128 + 256) * 4;
+constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (STAGE_FLOATS + 64 + 128 + 256 + 16) * 4;
 
 __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
   c.P = reinterpret_cast<__bf16*>(smem);
@@ -1219,6 +1318,7 @@ __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
   c.red = c.stage + STAGE_FLOATS;
   c.colacc = c.red + 64;
   c.rowacc = c.colacc + 128;
+  c.tlast = reinterpret_cast<unsigned long long*>(c.rowacc + 256);
 }
 
 template <bool SCALAR_TR>
@@ -1248,9 +1348,13 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
     if (flags & NM_F_PROFILE) c.t_last = clock64();
+    if ((flags & 64) && (threadIdx.x & 63) == 0) c.tlast[threadIdx.x >> 6] = clock64();
+    lds_barrier();
     relaunder(c);
     run_step<SCALAR_TR>(c, s);
+    tr(c, 62);
     __syncthreads();
+    tr(c, 63);
   }
 }
 
@@ -1387,6 +1491,18 @@ int nm_prof_read(unsigned long long* out32, int reset) {
   if (reset) {
     unsigned long long z[32] = {0};
     e = hipMemcpyToSymbol(HIP_SYMBOL(nm_prof_cycles), z, sizeof(z));
+  }
+  return (int)e;
+}
+
+/* NM_F_TRACE read-out: [8 waves][64 tags] interval cycles of workgroup (0,0); reset != 0 clears. */
+int nm_trace_read(unsigned long long* out512, int reset) {
+  if (!out512) return -1;
+  hipError_t e = hipMemcpyFromSymbol(out512, HIP_SYMBOL(nm_trace_cycles), sizeof(unsigned long long) * 512);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    static unsigned long long z[512];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(nm_trace_cycles), z, sizeof(z));
   }
   return (int)e;
 }
