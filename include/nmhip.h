@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define NM_MAX_MOD 4     /* experts / modalities per model (SM: 1, SE: 3, UCA: 4) */
+#define NM_MAX_MOD 8     /* decoders per model (SM: 1, SE: 3, UCA: 4, end-to-end: 2 banks x 3)   */
+#define NM_MAX_EXP 4     /* experts = modalities that also have an encoder                        */
 #define NM_MAX_HID 3     /* hidden layers per encoder / decoder stack            */
 #define NM_BATCH   256   /* rows per workgroup tile (= reference batch size)      */
 #define NM_MAX_WIDTH 127 /* max hidden width, and max latent + c_dim             */
@@ -70,11 +71,17 @@ typedef struct nm_modality {
   float* out_loc;         /* [rows_alloc][D]  decoder mean x_hat                         */
   float* out_sqerr;       /* [rows_alloc][D]  (x - x_hat)^2                              */
   float* out_rowdev;      /* [rows_alloc]     sum_d (x - x_hat)^2 / D                    */
+  /* optional extra loss gradient on the reconstruction, d L_extra / d x_hat, [rows_alloc][x_pitch]
+   * (regression head cVAE.py:2309-2346, contrastive hinge cVAE.py:2140-2200); added to the NLL term */
+  const float* dloc_extra;
 } nm_modality_t;
 
 /* One independent model (a (fold, procedure) cell of the sweep). */
 typedef struct nm_job {
-  int32_t M;              /* modalities                                                  */
+  int32_t M;              /* modalities = decoders                                       */
+  int32_t M_enc;          /* the first M_enc modalities also have an encoder (experts of the fusion);
+                             0 means M.  Decoder-only modalities model the second decoder bank of
+                             cVAE_multimodal_endtoend (cVAE.py:2047-2049)                 */
   int32_t C;              /* covariate width c_dim                                       */
   int32_t L;              /* hidden layers                                               */
   int32_t Z;              /* latent width                                                */
@@ -102,11 +109,12 @@ typedef struct nm_job {
   float*  out_mu;         /* NM_F_EXPORT: [rows_alloc][Z] joint mu      (may be NULL)    */
   float*  out_logvar;     /* NM_F_EXPORT: [rows_alloc][Z] joint logvar  (may be NULL)    */
   float*  out_z;          /* NM_F_EXPORT: [rows_alloc][Z] sampled z     (may be NULL)    */
+  const float* dz_extra;  /* optional d L_extra / d z, [rows_alloc][Z] (classifier head, cVAE.py:2117) */
   nm_modality_t mod[NM_MAX_MOD];
 } nm_job_t;
 
 /* loss_log row: total, kl (weighted sum as the reference reports it), ll (sum over m), then ll_m */
-#define NM_LOSS_STRIDE 8
+#define NM_LOSS_STRIDE 16
 #define NM_LOSS_TOTAL 0
 #define NM_LOSS_KL    1
 #define NM_LOSS_LL    2

@@ -9,12 +9,13 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NM_MAX_MOD = 4
+NM_MAX_MOD = 8
+NM_MAX_EXP = 4
 NM_MAX_HID = 3
 NM_BATCH = 256
 NM_MAX_WIDTH = 127
 NM_MAX_LATENT = 64
-NM_LOSS_STRIDE = 8
+NM_LOSS_STRIDE = 16
 
 NM_COMBINE = {"poe": 0, "gpoe": 1, "moe": 2, "mopoe": 3}
 
@@ -41,12 +42,13 @@ class NmModality(C.Structure):
         ("out_w", C.c_int64), ("out_b", C.c_int64),
         ("alpha", C.c_int64),
         ("out_loc", C.c_void_p), ("out_sqerr", C.c_void_p), ("out_rowdev", C.c_void_p),
+        ("dloc_extra", C.c_void_p),
     ]
 
 
 class NmJob(C.Structure):
     _fields_ = [
-        ("M", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("Z", C.c_int32),
+        ("M", C.c_int32), ("M_enc", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("Z", C.c_int32),
         ("H", C.c_int32 * NM_MAX_HID),
         ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32),
         ("loss_cap", C.c_int32), ("eps_cap", C.c_int32),
@@ -56,7 +58,7 @@ class NmJob(C.Structure):
         ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("grads", C.c_void_p),
         ("eps", C.c_void_p), ("seed", C.c_uint64),
         ("loss_log", C.c_void_p), ("workspace", C.c_void_p), ("workspace_stride", C.c_int64),
-        ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p),
+        ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p), ("dz_extra", C.c_void_p),
         ("mod", NmModality * NM_MAX_MOD),
     ]
 

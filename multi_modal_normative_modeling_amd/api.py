@@ -164,6 +164,14 @@ class _Base(nn.Module):
         if self._device is None:
             self.to(like.device if like.is_cuda else "cuda:0")
 
+    def _draw(self, B: int) -> torch.Tensor:
+        """The reparameterisation draw (torch.randn_like(mu), cVAE.py:1132).  Tests inject a fixed draw
+        through ``_eps_override``."""
+        ov = getattr(self, "_eps_override", None)
+        if ov is not None:
+            return torch.as_tensor(ov, dtype=torch.float32).to(self._dev())
+        return torch.randn(B, self.spec.latent, device=self._dev())
+
     def _dev(self):
         if self._device is None:
             self.to("cuda:0")          # raises NmError when no MI355X is visible
@@ -175,14 +183,14 @@ class _Base(nn.Module):
         tables = [Table(x, c, self._device) for x, c in zip(xes, cs)]
         # reuse one Job (buffers) across calls; only the tables change
         if self._job is None or self._job.combine != combine.lower() or self._job.tables[0].rows_alloc != tables[0].rows_alloc:
-            self._job = Job(self.spec, tables, combine=combine, state=self.state_dict(), lr=self._lr,
-                            kl_weight=self._kl_weight, loss_cap=1)
+            self._job = Job(self.spec, tables, combine=combine, state=_Base.state_dict(self), lr=self._lr,
+                            kl_weight=self._kl_weight, loss_cap=1, single_bypass=self.spec.kind != "endtoend")
             self._job.params = self._flat.data          # share storage with the module's parameters
             self._job.enable_exports()
         j = self._job
         j.tables = tables
         j.kl_weight = self._kl_weight if kl_w is None else kl_w
-        j.ll_weight = ll_w
+        j.ll_weight = getattr(self, "_ll_weight", 1.0) if ll_w == 1.0 else ll_w
         B, Z = int(xes[0].shape[0]), self.spec.latent
         if eps is None:
             eps = torch.randn(B, Z, device=self._device)            # torch.randn_like(mu), cVAE.py:1132
@@ -259,7 +267,7 @@ class cVAE_multimodal(_Base):
         if combine.lower() not in _lib.NM_COMBINE:
             raise ValueError("No such combination method")
         self.zero_grad()
-        eps = torch.randn(int(xes[0].shape[0]), self.spec.latent, device=self._dev())
+        eps = self._draw(int(xes[0].shape[0]))
         j, B = self._run(xes, cs, combine, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | _lib.NM_F_EXPORT, eps=eps)
         self._last = (list(xes), list(cs), combine, eps)
         x_recons = [NormalLike(j.out_loc[m][:B].clone(), self._scale(m)) for m in range(self.modalities)]
@@ -320,7 +328,7 @@ class cVAE(_Base):
 
     def forward(self, x, c):
         self.zero_grad()
-        eps = torch.randn(int(x.shape[0]), self.spec.latent, device=self._dev())
+        eps = self._draw(int(x.shape[0]))
         j, B = self._run([x], [c], "poe", _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | _lib.NM_F_EXPORT, eps=eps)
         self._last = ([x], [c], "poe", eps)
         return {"x_recon": NormalLike(j.out_loc[0][:B].clone(), self._scale(0)), "mu": j.out_mu[:B].clone(),
@@ -350,3 +358,267 @@ class cVAE(_Base):
         ct = torch.as_tensor(np.asarray(c), dtype=torch.long)
         mu, _ = self.encode(xt, ct)
         return self.decode(mu, ct).loc.cpu().numpy()
+
+
+# =========================================================================================================
+# Models with a head on top of the trunk: cVAE_multimodal_regression, cVAE_multimodal_endtoend
+# =========================================================================================================
+# The trunk (encoders, fusion, decoders, ELBO, their backward and Adam: all but 2-30 % of the parameters)
+# runs in the HIP kernel.  The heads depend on the trunk only through x_hat and z, so they enter the kernel
+# as extra loss gradients d L_head / d x_hat (nm_modality_t.dloc_extra) and d L_head / d z (nm_job_t.dz_extra):
+# launch A exports x_hat / z, the head (a few small dense layers, currently rocBLAS GEMMs through PyTorch-ROCm
+# with autograd) produces its loss and those two gradients, launch B runs the trunk's backward with them.
+
+
+class _HeadTrunkLoss(torch.autograd.Function):
+    """total = trunk part (from the kernel) + head part (torch graph).  backward: head first (fills the
+    gradients w.r.t. x_hat / z and the head's parameters), then the trunk launch with those as extras."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, trunk_value, head_box):
+        # the head loss travels in a list: as a tensor argument autograd would chain its graph behind this
+        # node and run it a second time after the explicit backward below
+        ctx.model, ctx.head_loss = model, head_box[0]
+        return trunk_value + head_box[0].detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.model._backward_with_head(ctx.head_loss, g)
+        return None, None, None, None
+
+
+class _AdamWithHead(_Adam):
+    def __init__(self, model, lr, head_params):
+        super().__init__(model, lr)
+        self.head = torch.optim.Adam(list(head_params), lr=lr)
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad()
+        self.head.zero_grad(set_to_none=set_to_none)
+
+    def step(self):
+        super().step()
+        self.head.step()
+
+
+class _HeadBase(_Base):
+    def _trunk_forward(self, xes, cs, combine, eps):
+        j, B = self._run(xes, cs, combine, _lib.NM_F_EXPORT, eps=eps)
+        locs = [j.out_loc[k][:B].clone().requires_grad_(True) for k in range(len(j.kmods))]
+        z = j.out_z[:B].clone().requires_grad_(True)
+        return j, B, locs, z
+
+    def _backward_with_head(self, head_loss, g):
+        xes, cs, combine, eps, locs, z = self._last
+        torch.autograd.backward(head_loss, g if torch.is_tensor(g) else torch.tensor(g))
+        j = self._job
+        ra = j.tables[0].rows_alloc
+        B = int(xes[0].shape[0])
+        for k, (m, _, _) in enumerate(j.kmods):
+            t = j.tables[m]
+            ex = torch.zeros(ra, t.x_pitch, device=self._device)
+            if locs[k].grad is not None:
+                ex[:B, :t.D] = locs[k].grad
+            j.dloc_extra[k] = ex
+        dz = torch.zeros(ra, self.spec.latent, device=self._device)
+        if z.grad is not None:
+            dz[:B] = z.grad
+        j.dz_extra = dz
+        j.kl_weight = self._kl_weight
+        j.ll_weight = getattr(self, "_ll_weight", 1.0)
+        j.touch()
+        self._run_keep_tables(_lib.NM_F_BACKWARD | _lib.NM_F_GRADS)
+        j.dz_extra = None
+        j.dloc_extra = [None] * len(j.kmods)
+        j.touch()
+        self._pending = j.grads
+        self._grads_ready = True
+        gv = self.layout.unflatten(self._pending)
+        for name, p in self._named_views():
+            if name in gv:
+                p.grad = gv[name]
+
+    def _run_keep_tables(self, flags):
+        j = self._job
+        j.step = 0
+        j.touch()
+        JobSet([j])._launch(0, 1, 1, flags)
+
+    def _named_views(self):
+        return [(n, p) for n, p in self.named_parameters() if n in self.layout.offsets]
+
+
+class cVAE_multimodal_regression(_HeadBase):
+    """cVAE.py:2211-2346: cVAE_multimodal + a regressor on the concatenated residuals."""
+
+    def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
+                 non_linear=False):
+        super().__init__()
+        self.input_dim_list, self.latent_dim, self.c_dim = list(input_dim_list), latent_dim, c_dim
+        self.hidden_dim = list(hidden_dim) + [latent_dim]
+        self.modalities, self.learning_rate, self.non_linear = modalities, learning_rate, non_linear
+        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "regression"),
+                    learning_rate, kl_weight=float(modalities))
+        self.regressor = nn.Sequential(nn.Linear(sum(input_dim_list), 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                       nn.Linear(64, 1))
+        self.mse_loss = nn.MSELoss()
+        self.optimizer1 = _AdamWithHead(self, learning_rate, self.regressor.parameters())
+
+    def to(self, device):
+        super().to(device)
+        self.regressor.to(self._device)
+        self.optimizer1.head = torch.optim.Adam(self.regressor.parameters(), lr=self.learning_rate)
+        return self
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict()
+        sd.update({f"regressor.{n}": v.detach().cpu().clone() for n, v in self.regressor.state_dict().items()})
+        return sd
+
+    def load_state_dict(self, state, strict: bool = True):
+        super().load_state_dict({k: v for k, v in state.items() if not k.startswith("regressor.")})
+        self.regressor.load_state_dict({k[len("regressor."):]: v for k, v in state.items() if k.startswith("regressor.")})
+        return self
+
+    def forward_multimodal(self, xes, cs, combine):
+        eps = self._draw(int(xes[0].shape[0]))
+        j, B, locs, z = self._trunk_forward(xes, cs, combine, eps)
+        xs = [x.to(self._device, torch.float32) for x in xes]
+        recon_concat = torch.cat([xs[m] - locs[m] for m in range(self.modalities)], dim=1)     # cVAE.py:2318-2319
+        fi_pred = self.regressor(recon_concat)
+        self._last = (list(xes), list(cs), combine, eps, locs, z)
+        return {"x_recons": [NormalLike(locs[m].detach(), self._scale(m)) for m in range(self.modalities)],
+                "mu_multimodal": j.out_mu[:B].clone(), "logvar_multimodal": j.out_logvar[:B].clone(), "fi_pred": fi_pred}
+
+    def loss_function_multimodal(self, xes, fwd_rtn, true_fi, lambda_reg=1.0):
+        row = self._job.loss_log[0]
+        reg = self.mse_loss(fwd_rtn["fi_pred"].squeeze(), true_fi.to(self._device).squeeze())
+        total = _HeadTrunkLoss.apply(self._anchor, self, row[0].clone(), [lambda_reg * reg])
+        return {"total": total, "kl": row[1].clone(), "ll": row[2].clone().reshape(1), "regression": reg}
+
+    def encode(self, x, c, m):
+        return cVAE_multimodal.encode(self, x, c, m)
+
+    def decode(self, z, c, m):
+        return cVAE_multimodal.decode(self, z, c, m)
+
+    def _unimodal(self, m):
+        return cVAE_multimodal._unimodal(self, m)
+
+
+class Classifier(nn.Module):
+    """cVAE.py:2004-2018."""
+
+    def __init__(self, latent_dim, classifier_layers, dropout_rate, num_classes=2):
+        super().__init__()
+        layers, sizes = [], [latent_dim] + list(classifier_layers)
+        for i in range(len(sizes) - 1):
+            layers += [nn.Linear(sizes[i], sizes[i + 1]), nn.BatchNorm1d(sizes[i + 1]), nn.ReLU(), nn.Dropout(dropout_rate)]
+        layers.append(nn.Linear(sizes[-1], num_classes))
+        self.classifier = nn.Sequential(*layers)
+
+    def forward(self, z):
+        return self.classifier(z)
+
+
+class cVAE_multimodal_endtoend(_HeadBase):
+    """cVAE.py:2021-2207: shared encoders, PoE (no single-expert bypass), health + disease decoder banks,
+    classifier on z, loss = w_rec (NLL_h + NLL_d) + w_kl KL + CE + w_c contrastive hinge."""
+
+    def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
+                 non_linear=False, classifier_layers=[128, 64], dropout_rate=0.5, num_classes=2):
+        super().__init__()
+        self.input_dim_list, self.latent_dim, self.c_dim = list(input_dim_list), latent_dim, c_dim
+        self.hidden_dim = list(hidden_dim) + [latent_dim]
+        self.modalities, self.learning_rate, self.non_linear, self.num_classes = modalities, learning_rate, non_linear, num_classes
+        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "endtoend"),
+                    learning_rate, kl_weight=0.1)
+        self._ll_weight = 0.1
+        self.classifier = Classifier(latent_dim, classifier_layers, dropout_rate, num_classes)
+        self.optimizer = _AdamWithHead(self, learning_rate, self.classifier.parameters())
+
+    def _build_tree(self):
+        v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
+        s, L = self.spec, len(self.spec.hidden)
+
+        def enc(m):
+            p = s.enc_prefix(m)
+            e = nn.Module()
+            e.encoder_layers = nn.ModuleList([_Holder(weight=v[f"{p}encoder_layers.{i}.weight"], bias=v[f"{p}encoder_layers.{i}.bias"])
+                                              for i in range(L)])
+            e.enc_mean_layer = _Holder(weight=v[f"{p}enc_mean_layer.weight"], bias=v[f"{p}enc_mean_layer.bias"])
+            e.enc_logvar_layer = _Holder(weight=v[f"{p}enc_logvar_layer.weight"], bias=v[f"{p}enc_logvar_layer.bias"])
+            return e
+
+        def dec(m, bank):
+            p = s.dec_prefix(m, bank)
+            d = nn.Module()
+            d.register_parameter("logvar_out", v[f"{p}logvar_out"])
+            d.decoder_layers = nn.ModuleList([_Holder(weight=v[f"{p}decoder_layers.{i}.weight"],
+                                                      bias=v[f"{p}decoder_layers.{i}.bias"]) for i in range(L)])
+            d.decoder_mean_layer = _Holder(weight=v[f"{p}decoder_mean_layer.weight"], bias=v[f"{p}decoder_mean_layer.bias"])
+            return d
+
+        self.encoder_list = nn.ModuleList([enc(m) for m in range(s.M)])
+        self.decoder_list_health = nn.ModuleList([dec(m, "health") for m in range(s.M)])
+        self.decoder_list_disease = nn.ModuleList([dec(m, "disease") for m in range(s.M)])
+
+    def to(self, device):
+        super().to(device)
+        self.classifier.to(self._device)
+        self.optimizer.head = torch.optim.Adam(self.classifier.parameters(), lr=self.learning_rate)
+        return self
+
+    def state_dict(self, *a, **k):
+        sd = _Base.state_dict(self)
+        sd.update({f"classifier.{n}": v.detach().cpu().clone() for n, v in self.classifier.state_dict().items()})
+        return sd
+
+    def load_state_dict(self, state, strict: bool = True):
+        _Base.load_state_dict(self, {k: v for k, v in state.items() if not k.startswith("classifier.")})
+        self.classifier.load_state_dict({k[len("classifier."):]: v for k, v in state.items() if k.startswith("classifier.")})
+        return self
+
+    def _scale_bank(self, m, bank):
+        return self._views()[f"{self.spec.dec_prefix(m, bank)}logvar_out"].exp().pow(0.5)
+
+    def forward(self, xes, cs):
+        eps = self._draw(int(xes[0].shape[0]))
+        j, B, locs, z = self._trunk_forward(xes, cs, "poe", eps)
+        M = self.modalities
+        logits = self.classifier(z)
+        self._last = (list(xes), list(cs), "poe", eps, locs, z)
+        return {"x_recons_health": [NormalLike(locs[m], self._scale_bank(m, "health")) for m in range(M)],
+                "x_recons_disease": [NormalLike(locs[M + m], self._scale_bank(m, "disease")) for m in range(M)],
+                "mu": j.out_mu[:B].clone(), "logvar": j.out_logvar[:B].clone(), "logits": logits}
+
+    def calc_kl(self, mu, logvar):
+        return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1).mean()
+
+    def compute_deviation(self, x, x_recon):
+        return ((x - x_recon.mean) ** 2).mean(dim=1)                          # cVAE.py:2134-2138
+
+    def loss_function(self, xes, fwd_rtn, labels, margin=1.0, weightcontrastive=0.1, weight_kl=0.1, weight_rec=0.1):
+        if abs(weight_kl - self._kl_weight) > 0 or abs(weight_rec - 0.1) > 0:
+            self._kl_weight = float(weight_kl)
+        M = self.modalities
+        xs = [x.to(self._device, torch.float32) for x in xes]
+        labels = labels.to(self._device)
+        row = self._job.loss_log[0]
+        ll_m = row[3:3 + 2 * M]
+        recon_h, recon_d = -ll_m[:M].sum(), -ll_m[M:].sum()
+        dev_h = torch.stack([self.compute_deviation(xs[m], fwd_rtn["x_recons_health"][m]) for m in range(M)]).mean(dim=0)
+        dev_d = torch.stack([self.compute_deviation(xs[m], fwd_rtn["x_recons_disease"][m]) for m in range(M)]).mean(dim=0)
+        contrastive = torch.mean((1 - labels) * torch.relu(margin + dev_h - dev_d) + labels * torch.relu(margin + dev_d - dev_h))
+        kl = self.calc_kl(fwd_rtn["mu"], fwd_rtn["logvar"])
+        ce = torch.nn.functional.cross_entropy(fwd_rtn["logits"], labels)
+        self._ll_weight = float(weight_rec)
+        trunk = weight_rec * (recon_h + recon_d) + weight_kl * kl
+        total = _HeadTrunkLoss.apply(self._anchor, self, trunk.detach(), [ce + weightcontrastive * contrastive])
+        return {"total_loss": total, "recon_loss_health": recon_h.clone(), "recon_loss_disease": recon_d.clone(),
+                "kl_loss": kl, "classification_loss": ce, "contrastive_loss": contrastive}
+
+    def predict(self, xes, cs):
+        with torch.no_grad():
+            j, B = self._run(xes, cs, "poe", _lib.NM_F_EXPORT)
+            return self.classifier(j.out_mu[:B].clone())

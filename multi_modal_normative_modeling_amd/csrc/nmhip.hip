@@ -764,30 +764,31 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
 }
 
 // ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
+__device__ __forceinline__ int experts(const nm_job_t* J) { return J->M_enc > 0 ? J->M_enc : J->M; }
 struct Fuse { float mu, lv, var; };
-struct Lat { float mu[NM_MAX_MOD], lv[NM_MAX_MOD]; };     // always indexed by unrolled constants
-__device__ __forceinline__ void softmax_alpha(const nm_job_t* J, float (&al)[NM_MAX_MOD]) {
+struct Lat { float mu[NM_MAX_EXP], lv[NM_MAX_EXP]; };     // always indexed by unrolled constants
+__device__ __forceinline__ void softmax_alpha(const nm_job_t* J, float (&al)[NM_MAX_EXP]) {
   float mx = -INFINITY;
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m)
-    if (m < J->M) mx = fmaxf(mx, asg(J->params)[J->mod[m].alpha]);
+  for (int m = 0; m < NM_MAX_EXP; ++m)
+    if (m < experts(J)) mx = fmaxf(mx, asg(J->params)[J->mod[m].alpha]);
   float s = 0.f;
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m) {
-    al[m] = (m < J->M) ? expf(asg(J->params)[J->mod[m].alpha] - mx) : 0.f;
+  for (int m = 0; m < NM_MAX_EXP; ++m) {
+    al[m] = (m < experts(J)) ? expf(asg(J->params)[J->mod[m].alpha] - mx) : 0.f;
     s += al[m];
   }
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m) al[m] /= s;
+  for (int m = 0; m < NM_MAX_EXP; ++m) al[m] /= s;
 }
-__device__ __forceinline__ Fuse fuse_fwd(const nm_job_t* J, const Lat& L, const float (&al)[NM_MAX_MOD]) {
-  const int M = J->M;
+__device__ __forceinline__ Fuse fuse_fwd(const nm_job_t* J, const Lat& L, const float (&al)[NM_MAX_EXP]) {
+  const int M = experts(J);
   Fuse f;
   if (M == 1 && J->single_bypass) { f.mu = L.mu[0]; f.var = expf(L.lv[0]); f.lv = logf(f.var); return f; }
   const int cb = J->combine;
   float S = 0.f, Smu = 0.f, sm = 0.f, sv = 0.f;
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m) {
+  for (int m = 0; m < NM_MAX_EXP; ++m) {
     if (m < M) {
       float var = expf(L.lv[m]);
       float w = (cb == NM_COMBINE_GPOE) ? al[m] / var : 1.0f / var;
@@ -804,18 +805,18 @@ __device__ __forceinline__ Fuse fuse_fwd(const nm_job_t* J, const Lat& L, const 
   return f;
 }
 // backward of the fusion: (d mu_j, d lv_j) -> (d mu_m, d lv_m) and d alpha_m (gPoE) for EVERY expert
-struct FuseGrad { float dmu[NM_MAX_MOD], dlv[NM_MAX_MOD], dal[NM_MAX_MOD]; };
-__device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, const float (&al)[NM_MAX_MOD], float dmu_j,
+struct FuseGrad { float dmu[NM_MAX_EXP], dlv[NM_MAX_EXP], dal[NM_MAX_EXP]; };
+__device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, const float (&al)[NM_MAX_EXP], float dmu_j,
                                              float dlv_j) {
-  const int M = J->M;
+  const int M = experts(J);
   FuseGrad G;
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m) { G.dmu[m] = 0.f; G.dlv[m] = 0.f; G.dal[m] = 0.f; }
+  for (int m = 0; m < NM_MAX_EXP; ++m) { G.dmu[m] = 0.f; G.dlv[m] = 0.f; G.dal[m] = 0.f; }
   if (M == 1 && J->single_bypass) { G.dmu[0] = dmu_j; G.dlv[0] = dlv_j; return G; }
   const int cb = J->combine;
   float S = 0.f, Smu = 0.f, sv = 0.f;
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m) {
+  for (int m = 0; m < NM_MAX_EXP; ++m) {
     if (m < M) {
       float w = expf(-L.lv[m]) * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);
       S += w; Smu += L.mu[m] * w;
@@ -824,7 +825,7 @@ __device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, co
   }
   if (cb == NM_COMBINE_MOE) {
 #pragma unroll
-    for (int m = 0; m < NM_MAX_MOD; ++m)
+    for (int m = 0; m < NM_MAX_EXP; ++m)
       if (m < M) { G.dmu[m] = dmu_j / M; G.dlv[m] = dlv_j * expf(L.lv[m]) / sv; }   // d log(mean var) / d lv_m
     return G;
   }
@@ -838,7 +839,7 @@ __device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, co
     e_lv = dlv_j / ((M + 1) * var_j);
   }
 #pragma unroll
-  for (int m = 0; m < NM_MAX_MOD; ++m) {
+  for (int m = 0; m < NM_MAX_EXP; ++m) {
     if (m < M) {
       float pm = expf(-L.lv[m]);
       float r = var_p * pm * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);     // sigma^2 * p_m
@@ -849,10 +850,10 @@ __device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, co
   }
   return G;
 }
-__device__ __forceinline__ float pick(const float (&a)[NM_MAX_MOD], int m) {
+__device__ __forceinline__ float pick(const float (&a)[NM_MAX_EXP], int m) {
   float r = a[0];
 #pragma unroll
-  for (int q = 1; q < NM_MAX_MOD; ++q) r = (q == m) ? a[q] : r;
+  for (int q = 1; q < NM_MAX_EXP; ++q) r = (q == m) ? a[q] : r;
   return r;
 }
 
@@ -863,6 +864,7 @@ template <bool SCALAR_TR>
 __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const nm_job_t* J = c.job;
   const int M = J->M, L = J->L, Z = J->Z, C = J->C;
+  const int Me = experts(J);                    // modalities that have an encoder
   const bool nl = J->non_linear != 0;
   const bool bwd = (c.flags & NM_F_BACKWARD) != 0;
   const bool exportf = (c.flags & NM_F_EXPORT) != 0;
@@ -881,7 +883,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   gcf32 prm = asg(J->params);
 
   // ================= encoders =================
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < Me; ++m) {
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     gbf16 save0 = bwd ? ws_enc + (int64_t)(m * L + 0) * ROWS * PW : (gbf16)nullptr;
@@ -898,13 +900,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
 
   // ================= fusion + reparameterisation + KL =================
-  float al[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
-  if (J->combine == NM_COMBINE_GPOE && !(M == 1 && J->single_bypass)) softmax_alpha(J, al);
+  float al[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
+  if (J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass)) softmax_alpha(J, al);
   auto load_lat = [&](Lat& Lt, int r, int z) {
 #pragma unroll
-    for (int m = 0; m < NM_MAX_MOD; ++m) {
-      Lt.mu[m] = (m < M) ? ws_mu_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
-      Lt.lv[m] = (m < M) ? ws_lv_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
+    for (int m = 0; m < NM_MAX_EXP; ++m) {
+      Lt.mu[m] = (m < Me) ? ws_mu_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
+      Lt.lv[m] = (m < Me) ? ws_lv_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
     }
   };
   float kl_part = 0.f;
@@ -1053,11 +1055,14 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             const bool rv = r < c.nrows;
             nvalid += rv ? 1 : 0;
             bf16x4 pk;
+            f32x4 ex = {0.f, 0.f, 0.f, 0.f};
+            if (md.dloc_extra)               // extra loss gradient on x_hat (regression head / contrastive hinge)
+              ex = *(const GAS f32x4*)(asg(md.dloc_extra) + (int64_t)(c.row0 + r) * xp + min(dg0, xp - 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float diff = rv ? acc[t][rt][i] - xcur[rt][i] : 0.f;
               colq[i] = fmaf(diff, diff, colq[i]);
-              pk[i] = (__bf16)(diff * coef[i]);
+              pk[i] = (__bf16)(diff * coef[i] + ((rv && dg0 + i < D) ? ex[i] : 0.f));
             }
             if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
           }
@@ -1194,38 +1199,39 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   prof(c, PH_ALPHA);
 
   // ================= fusion backward: alpha gradients (gPoE) =================
-  const bool fused = !(M == 1 && J->single_bypass);
+  const bool fused = !(Me == 1 && J->single_bypass);
   const float klw = J->kl_weight * c.inv_b;
   if (fused && J->combine == NM_COMBINE_GPOE) {
     relaunder(c);
-    float dal[NM_MAX_MOD] = {0.f, 0.f, 0.f, 0.f};
+    float dal[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
     for (int e = c.tid; e < c.nrows * Z; e += WG) {
       int r = idiv(e, Z, rZ), z = e - r * Z;
       Lat Lt;
       load_lat(Lt, r, z);
       float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
+      if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
       float dmu_j = dz + klw * mj;
       float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
       FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
 #pragma unroll
-      for (int m = 0; m < NM_MAX_MOD; ++m) dal[m] += G.dal[m];
+      for (int m = 0; m < NM_MAX_EXP; ++m) dal[m] += G.dal[m];
     }
-    float tot[NM_MAX_MOD];
+    float tot[NM_MAX_EXP];
 #pragma unroll
-    for (int m = 0; m < NM_MAX_MOD; ++m) tot[m] = block_sum(c, dal[m]);
+    for (int m = 0; m < NM_MAX_EXP; ++m) tot[m] = block_sum(c, dal[m]);
     if (c.tid == 0) {
       float dot = 0.f;
 #pragma unroll
-      for (int m = 0; m < NM_MAX_MOD; ++m) dot += al[m] * tot[m];
+      for (int m = 0; m < NM_MAX_EXP; ++m) dot += al[m] * tot[m];
 #pragma unroll
-      for (int m = 0; m < NM_MAX_MOD; ++m)
-        if (m < M) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
+      for (int m = 0; m < NM_MAX_EXP; ++m)
+        if (m < Me) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
     }
     __syncthreads();
   }
 
   // ================= encoders, backward =================
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < Me; ++m) {
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int Hh = J->H[L - 1];
@@ -1247,6 +1253,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         Lat Lt;
         load_lat(Lt, r, z);
         float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
+        if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
         float dmu_j = dz + klw * mj;
         float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
         FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
@@ -1518,7 +1525,7 @@ const char* nm_status_string(int status) {
   switch (status) {
     case 0: return "ok";
     case -1: return "null pointer";
-    case -2: return "modalities out of range (1..NM_MAX_MOD)";
+    case -2: return "modalities out of range (1..NM_MAX_MOD decoders, 1..NM_MAX_EXP experts)";
     case -3: return "hidden layers out of range (1..NM_MAX_HID)";
     case -4: return "hidden width out of range (1..NM_MAX_WIDTH)";
     case -5: return "latent out of range (1..NM_MAX_LATENT)";
@@ -1534,6 +1541,7 @@ const char* nm_status_string(int status) {
 int nm_validate_job(const nm_job_t* j) {
   if (!j) return -1;
   if (j->M < 1 || j->M > NM_MAX_MOD) return -2;
+  if (j->M_enc < 0 || j->M_enc > j->M || (j->M_enc == 0 ? j->M : j->M_enc) > NM_MAX_EXP) return -2;
   if (j->L < 1 || j->L > NM_MAX_HID) return -3;
   for (int i = 0; i < j->L; ++i)
     if (j->H[i] < 1 || j->H[i] > NM_MAX_WIDTH) return -4;

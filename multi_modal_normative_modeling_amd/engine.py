@@ -98,6 +98,9 @@ class Job:
         self.lr, self.betas, self.adam_eps = float(lr), (float(betas[0]), float(betas[1])), float(adam_eps)
         # cVAE_multimodal adds KL once per modality (cVAE.py:1189-1195); class cVAE once (cVAE.py:497-500)
         self.kl_weight = float(spec.M if kl_weight is None else kl_weight)
+        self.kmods = spec.kernel_modalities()         # decoders the kernel runs: (table, has_encoder, prefix)
+        self.dz_extra: Optional[torch.Tensor] = None  # d L_extra / d z          [rows_alloc, Z]
+        self.dloc_extra: List[Optional[torch.Tensor]] = [None] * len(self.kmods)   # d L_extra / d x_hat [rows_alloc, x_pitch]
         self.ll_weight = float(ll_weight)
         self.single_bypass = bool(single_bypass)
         self.seed = int(seed)
@@ -113,9 +116,10 @@ class Job:
         self._ensure_workspace(n_tiles_ws)
         # optional exports
         self.out_mu = self.out_logvar = self.out_z = None
-        self.out_loc: List[Optional[torch.Tensor]] = [None] * spec.M
-        self.out_sqerr: List[Optional[torch.Tensor]] = [None] * spec.M
-        self.out_rowdev: List[Optional[torch.Tensor]] = [None] * spec.M
+        nk = len(self.kmods)
+        self.out_loc: List[Optional[torch.Tensor]] = [None] * nk
+        self.out_sqerr: List[Optional[torch.Tensor]] = [None] * nk
+        self.out_rowdev: List[Optional[torch.Tensor]] = [None] * nk
 
     # -- buffers -------------------------------------------------------------------------------
     def _ensure_workspace(self, n_tiles: int):
@@ -123,7 +127,7 @@ class Job:
             return
         lib = _lib.load()
         probe = _lib.NmJob()
-        probe.M, probe.L, probe.Z = self.spec.M, len(self.spec.hidden), self.spec.latent
+        probe.M, probe.L, probe.Z = len(self.kmods), len(self.spec.hidden), self.spec.latent
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
@@ -157,15 +161,16 @@ class Job:
             self.out_mu = torch.zeros(ra, Z, device=self.device)
             self.out_logvar = torch.zeros(ra, Z, device=self.device)
             self.out_z = torch.zeros(ra, Z, device=self.device)
-        for m, t in enumerate(self.tables):
-            self.out_loc[m] = torch.zeros(ra, t.D, device=self.device) if loc else None
-            self.out_sqerr[m] = torch.zeros(ra, t.D, device=self.device) if sqerr else None
-            self.out_rowdev[m] = torch.zeros(ra, device=self.device) if rowdev else None
+        for j, (m, _, _) in enumerate(self.kmods):
+            t = self.tables[m]
+            self.out_loc[j] = torch.zeros(ra, t.D, device=self.device) if loc else None
+            self.out_sqerr[j] = torch.zeros(ra, t.D, device=self.device) if sqerr else None
+            self.out_rowdev[j] = torch.zeros(ra, device=self.device) if rowdev else None
 
     # -- descriptor ----------------------------------------------------------------------------
     def struct(self) -> _lib.NmJob:
         s, j = self.spec, _lib.NmJob()
-        j.M, j.C, j.L, j.Z = s.M, s.c_dim, len(s.hidden), s.latent
+        j.M, j.M_enc, j.C, j.L, j.Z = len(self.kmods), s.M, s.c_dim, len(s.hidden), s.latent
         for i, h in enumerate(s.hidden):
             j.H[i] = h
         j.combine = _lib.NM_COMBINE[self.combine]
@@ -186,14 +191,17 @@ class Job:
         j.out_mu = self.out_mu.data_ptr() if self.out_mu is not None else None
         j.out_logvar = self.out_logvar.data_ptr() if self.out_logvar is not None else None
         j.out_z = self.out_z.data_ptr() if self.out_z is not None else None
-        for m, t in enumerate(self.tables):
-            md = j.mod[m]
+        j.dz_extra = self.dz_extra.data_ptr() if self.dz_extra is not None else None
+        for k, (m, _, _) in enumerate(self.kmods):
+            t = self.tables[m]
+            md = j.mod[k]
             md.D, md.Kx, md.x_pitch = t.D, t.Kx, t.x_pitch
             md.x_f32, md.xb = t.x_f32.data_ptr(), t.xb.data_ptr()
-            self.layout.fill_modality(md, m)
-            md.out_loc = self.out_loc[m].data_ptr() if self.out_loc[m] is not None else None
-            md.out_sqerr = self.out_sqerr[m].data_ptr() if self.out_sqerr[m] is not None else None
-            md.out_rowdev = self.out_rowdev[m].data_ptr() if self.out_rowdev[m] is not None else None
+            self.layout.fill_modality(md, k)
+            md.out_loc = self.out_loc[k].data_ptr() if self.out_loc[k] is not None else None
+            md.out_sqerr = self.out_sqerr[k].data_ptr() if self.out_sqerr[k] is not None else None
+            md.out_rowdev = self.out_rowdev[k].data_ptr() if self.out_rowdev[k] is not None else None
+            md.dloc_extra = self.dloc_extra[k].data_ptr() if self.dloc_extra[k] is not None else None
         _lib.check(_lib.load().nm_validate_job(C.byref(j)), "nm_validate_job")
         return j
 

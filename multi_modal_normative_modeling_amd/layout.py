@@ -28,15 +28,18 @@ class ModelSpec:
     latent: int
     c_dim: int
     non_linear: bool = True
-    kind: str = "multimodal"      # "single" = class cVAE, "multimodal" = cVAE_multimodal
+    # "single" = class cVAE, "multimodal" = cVAE_multimodal, "regression" = cVAE_multimodal_regression (trunk),
+    # "endtoend" = cVAE_multimodal_endtoend (trunk: shared encoders + health / disease decoder banks)
+    kind: str = "multimodal"
 
     @property
     def M(self) -> int:
         return len(self.input_dims)
 
     def validate(self):
-        if not (1 <= self.M <= _lib.NM_MAX_MOD):
-            raise ValueError(f"modalities must be 1..{_lib.NM_MAX_MOD}, got {self.M}")
+        n_dec = self.M * (2 if self.kind == "endtoend" else 1)
+        if not (1 <= self.M <= _lib.NM_MAX_EXP) or n_dec > _lib.NM_MAX_MOD:
+            raise ValueError(f"modalities must be 1..{_lib.NM_MAX_EXP} (and at most {_lib.NM_MAX_MOD} decoders), got {self.M}")
         if not (1 <= len(self.hidden) <= _lib.NM_MAX_HID):
             raise ValueError(f"hidden layers must be 1..{_lib.NM_MAX_HID}, got {len(self.hidden)}")
         if any(h < 1 or h > _lib.NM_MAX_WIDTH for h in self.hidden):
@@ -59,8 +62,20 @@ class ModelSpec:
     def enc_prefix(self, m: int) -> str:
         return "encoder." if self.kind == "single" else f"encoder_list.{m}."
 
-    def dec_prefix(self, m: int) -> str:
-        return "decoder." if self.kind == "single" else f"decoder_list.{m}."
+    def dec_prefix(self, m: int, bank: str = "") -> str:
+        if self.kind == "single":
+            return "decoder."
+        if self.kind == "endtoend":
+            return f"decoder_list_{bank}.{m}."
+        return f"decoder_list.{m}."
+
+    def kernel_modalities(self):
+        """(table index, has_encoder, decoder prefix) of every decoder the kernel runs.  The end-to-end
+        model's disease bank follows the health bank as decoder-only modalities on the same tables."""
+        if self.kind == "endtoend":
+            return ([(m, True, self.dec_prefix(m, "health")) for m in range(self.M)] +
+                    [(m, False, self.dec_prefix(m, "disease")) for m in range(self.M)])
+        return [(m, True, self.dec_prefix(m)) for m in range(self.M)]
 
 
 def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -77,8 +92,8 @@ def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
             out.append((f"{p}{h}.weight", (s[-1], s[-2])))
             out.append((f"{p}{h}.bias", (s[-1],)))
 
-    def dec(m):
-        p, s = spec.dec_prefix(m), spec.dec_sizes(m)
+    def dec(m, bank=""):
+        p, s = spec.dec_prefix(m, bank), spec.dec_sizes(m)
         out.append((f"{p}logvar_out", (1, spec.input_dims[m])))
         for i in range(L):
             out.append((f"{p}decoder_layers.{i}.weight", (s[i + 1], s[i])))
@@ -96,6 +111,19 @@ def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
             enc(m)
         for m in range(spec.M):
             dec(m)
+    elif spec.kind == "regression":          # cVAE.py:2230-2253: encoder_list, decoder_list, alpha_m_list (+ regressor: torch side)
+        for m in range(spec.M):
+            enc(m)
+        for m in range(spec.M):
+            dec(m)
+        for m in range(spec.M):
+            out.append((f"alpha_m_list.{m}", (1,)))
+    elif spec.kind == "endtoend":            # cVAE.py:2044-2054: encoder_list, decoder_list_health, decoder_list_disease (+ classifier)
+        for m in range(spec.M):
+            enc(m)
+        for bank in ("health", "disease"):
+            for m in range(spec.M):
+                dec(m, bank)
     else:
         raise ValueError(f"unknown model kind {spec.kind!r}")
     return out
@@ -169,16 +197,20 @@ class ParamLayout:
                 out[n] = (torch.rand(shape, generator=g) * 2 - 1) * bound
         return out
 
-    def fill_modality(self, md: "_lib.NmModality", m: int):
+    def fill_modality(self, md: "_lib.NmModality", j: int):
+        """Tensor offsets of kernel modality j (see ModelSpec.kernel_modalities)."""
         spec, o = self.spec, self.offsets
-        ep, dp = spec.enc_prefix(m), spec.dec_prefix(m)
+        m, has_enc, dp = spec.kernel_modalities()[j]
+        ep = spec.enc_prefix(m)
         for i in range(len(spec.hidden)):
-            md.enc_w[i] = o[f"{ep}encoder_layers.{i}.weight"]
-            md.enc_b[i] = o[f"{ep}encoder_layers.{i}.bias"]
+            md.enc_w[i] = o[f"{ep}encoder_layers.{i}.weight"] if has_enc else 0
+            md.enc_b[i] = o[f"{ep}encoder_layers.{i}.bias"] if has_enc else 0
             md.dec_w[i] = o[f"{dp}decoder_layers.{i}.weight"]
             md.dec_b[i] = o[f"{dp}decoder_layers.{i}.bias"]
-        md.mu_w, md.mu_b = o[f"{ep}enc_mean_layer.weight"], o[f"{ep}enc_mean_layer.bias"]
-        md.lv_w, md.lv_b = o[f"{ep}enc_logvar_layer.weight"], o[f"{ep}enc_logvar_layer.bias"]
+        md.mu_w = o[f"{ep}enc_mean_layer.weight"] if has_enc else 0
+        md.mu_b = o[f"{ep}enc_mean_layer.bias"] if has_enc else 0
+        md.lv_w = o[f"{ep}enc_logvar_layer.weight"] if has_enc else 0
+        md.lv_b = o[f"{ep}enc_logvar_layer.bias"] if has_enc else 0
         md.logvar_out = o[f"{dp}logvar_out"]
         md.out_w, md.out_b = o[f"{dp}decoder_mean_layer.weight"], o[f"{dp}decoder_mean_layer.bias"]
-        md.alpha = o.get(f"alpha_m_list.{m}", -1)
+        md.alpha = o.get(f"alpha_m_list.{m}", -1) if has_enc else -1

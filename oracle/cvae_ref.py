@@ -468,3 +468,90 @@ def reconstruction_deviation(x, x_pred):
 def reconstruction_deviation_roi(x, x_pred):
     """utils_vae.py:151-152."""
     return (x - x_pred) ** 2
+
+
+# ----------------------------------------------------------------------------------------
+# A14  cVAE_multimodal_regression      (cVAE.py:2211-2346)
+# ----------------------------------------------------------------------------------------
+def forward_regression(P, spec: Spec, xes, cs, combine: str, eps):
+    """cVAE.py:2309-2328: trunk as cVAE_multimodal, then fi_pred = regressor(cat_m(x_m - loc_m)),
+    regressor = Linear(sum D, 128) - ReLU - Linear(128, 64) - ReLU - Linear(64, 1)."""
+    trunk = Spec(spec.input_dims, spec.hidden, spec.latent, spec.c_dim, spec.non_linear, kind="multimodal")
+    fwd = forward_multimodal(P, trunk, xes, cs, combine, eps)
+    diffs = torch.cat([xes[m] - fwd["locs"][m] for m in range(spec.M)], dim=1)
+    h = torch.relu(torch.nn.functional.linear(diffs, P["regressor.0.weight"], P["regressor.0.bias"]))
+    h = torch.relu(torch.nn.functional.linear(h, P["regressor.2.weight"], P["regressor.2.bias"]))
+    fwd["fi_pred"] = torch.nn.functional.linear(h, P["regressor.4.weight"], P["regressor.4.bias"])
+    return fwd
+
+
+def loss_regression(spec: Spec, xes, fwd, true_fi, lambda_reg: float = 1.0):
+    """cVAE.py:2330-2346: sum_m (KL - LL_m) + lambda * MSE(fi_pred, FI)."""
+    trunk = Spec(spec.input_dims, spec.hidden, spec.latent, spec.c_dim, spec.non_linear, kind="multimodal")
+    loss = loss_multimodal(trunk, xes, fwd)
+    reg = torch.nn.functional.mse_loss(fwd["fi_pred"].squeeze(), true_fi.squeeze())
+    loss["regression"] = reg
+    loss["total"] = loss["total"] + lambda_reg * reg
+    return loss
+
+
+# ----------------------------------------------------------------------------------------
+# A13  cVAE_multimodal_endtoend        (cVAE.py:2004-2207)
+# ----------------------------------------------------------------------------------------
+def classifier_fwd(P, spec: Spec, z, training: bool, bn_stats: Optional[dict] = None):
+    """Classifier (cVAE.py:2004-2018): (Linear - BatchNorm1d - ReLU - Dropout)* - Linear.  Dropout is the
+    identity here (rate 0 in training parity runs, eval otherwise).  In training mode BatchNorm uses the
+    batch statistics; in eval mode the running statistics passed in `bn_stats`."""
+    h = z
+    li = 0
+    for _ in range(len(spec.classifier_layers)):
+        p = f"classifier.classifier.{li}"
+        h = torch.nn.functional.linear(h, P[p + ".weight"], P[p + ".bias"])
+        q = f"classifier.classifier.{li + 1}"
+        if training:
+            h = torch.nn.functional.batch_norm(h, None, None, P[q + ".weight"], P[q + ".bias"], True, 0.1, 1e-5)
+        else:
+            h = torch.nn.functional.batch_norm(h, bn_stats[q + ".running_mean"], bn_stats[q + ".running_var"],
+                                               P[q + ".weight"], P[q + ".bias"], False, 0.1, 1e-5)
+        h = torch.relu(h)
+        li += 4
+    p = f"classifier.classifier.{li}"
+    return torch.nn.functional.linear(h, P[p + ".weight"], P[p + ".bias"])
+
+
+def forward_endtoend(P, spec: Spec, xes, cs, eps, training: bool = True, bn_stats=None):
+    """cVAE.py:2106-2123: shared encoders -> PoE WITHOUT the single-expert bypass (cVAE.py:2083-2090)
+    -> z -> health and disease decoder banks + classifier(z)."""
+    enc = [encoder_fwd(P, spec, m, xes[m], cs[m]) for m in range(spec.M)]
+    mus = torch.stack([e[0] for e in enc])
+    logvars = torch.stack([e[1] for e in enc])
+    T = 1 / torch.exp(logvars)
+    mu = torch.sum(mus * T, dim=0) / torch.sum(T, dim=0)
+    logvar = torch.log(1 / torch.sum(T, dim=0))
+    z = reparameterise(mu, logvar, eps)
+    locs_h, locs_d, scales_h, scales_d = [], [], [], []
+    for m in range(spec.M):
+        lh, sh = decoder_fwd(P, spec, m, z, cs[m], "health")
+        ld, sd = decoder_fwd(P, spec, m, z, cs[m], "disease")
+        locs_h.append(lh); locs_d.append(ld); scales_h.append(sh); scales_d.append(sd)
+    return {"locs_h": locs_h, "locs_d": locs_d, "scales_h": scales_h, "scales_d": scales_d, "mu": mu, "logvar": logvar,
+            "z": z, "logits": classifier_fwd(P, spec, z, training, bn_stats)}
+
+
+def loss_endtoend(spec: Spec, xes, fwd, labels, margin=1.0, weightcontrastive=0.1, weight_kl=0.1, weight_rec=0.1):
+    """cVAE.py:2140-2200."""
+    rh = rd = 0.0
+    dh, dd = [], []
+    for m in range(spec.M):
+        rh = rh + (-normal_log_prob(xes[m], fwd["locs_h"][m], fwd["scales_h"][m]).sum(dim=1).mean())
+        rd = rd + (-normal_log_prob(xes[m], fwd["locs_d"][m], fwd["scales_d"][m]).sum(dim=1).mean())
+        dh.append(((xes[m] - fwd["locs_h"][m]) ** 2).mean(dim=1))           # compute_deviation, cVAE.py:2134-2138
+        dd.append(((xes[m] - fwd["locs_d"][m]) ** 2).mean(dim=1))
+    dev_h = torch.stack(dh).mean(dim=0)
+    dev_d = torch.stack(dd).mean(dim=0)
+    contrastive = torch.mean((1 - labels) * torch.relu(margin + dev_h - dev_d) + labels * torch.relu(margin + dev_d - dev_h))
+    kl = -0.5 * torch.sum(1 + fwd["logvar"] - fwd["mu"].pow(2) - fwd["logvar"].exp(), dim=1).mean()
+    ce = torch.nn.functional.cross_entropy(fwd["logits"], labels)
+    total = weight_rec * (rh + rd) + weight_kl * kl + ce + weightcontrastive * contrastive
+    return {"total_loss": total, "recon_loss_health": rh, "recon_loss_disease": rd, "kl_loss": kl,
+            "classification_loss": ce, "contrastive_loss": contrastive}

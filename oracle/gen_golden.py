@@ -194,6 +194,88 @@ def case_deviation(ref, name, dims, c_dim, hidden, Z, N, combine, seed):
     print("wrote", name)
 
 
+def case_regression(ref, name, dims, c_dim, hidden, Z, B, combine, n_steps, seed):
+    """cVAE_multimodal_regression (cVAE.py:2211-2346): trunk + regressor on concatenated residuals."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    M = len(dims)
+    model = ref.cVAE_multimodal_regression(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
+                                           learning_rate=1e-4, modalities=M, non_linear=True)
+    out = {"meta": np.array([M, c_dim, Z, B, n_steps]), "dims": np.array(dims), "hidden": np.array(hidden),
+           "combine": np.array(combine)}
+    out.update(sd_np(model, "w0:"))
+    xs = [torch.randn(n_steps, B, d, generator=g) for d in dims]
+    c = torch.rand(n_steps, B, c_dim, generator=g) * 2.0            # raw float covariates (AGE, PTGENDER), :107
+    fi = torch.randn(n_steps, B, 1, generator=g) * 0.5 + 1.0
+    eps = torch.randn(n_steps, B, Z, generator=g)
+    for m in range(M):
+        out[f"x{m}"] = xs[m].numpy()
+    out.update({"c": c.numpy(), "eps": eps.numpy(), "fi": fi.numpy()})
+    for s_ in range(n_steps):
+        xes = [xs[m][s_] for m in range(M)]
+        with fixed_eps([eps[s_]]):
+            fwd = model.forward_multimodal(xes, [c[s_]] * M, combine)
+        loss = model.loss_function_multimodal(xes, fwd, fi[s_], lambda_reg=1.0)
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        if s_ == 0:
+            out["fi_pred"] = fwd["fi_pred"].detach().numpy().copy()
+            out["mu"] = fwd["mu_multimodal"].detach().numpy().copy()
+            for m in range(M):
+                out[f"loc{m}"] = fwd["x_recons"][m].loc.detach().numpy().copy()
+            out.update(grads_np(model, "g0:"))
+        out[f"loss{s_}"] = np.array([float(loss["total"]), float(loss["kl"]), float(loss["ll"]), float(loss["regression"])])
+        model.optimizer1.step()
+    out.update(sd_np(model, f"w{n_steps}:"))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name, out["loss0"])
+
+
+def case_endtoend(ref, name, dims, c_dim, hidden, Z, B, layers, n_steps, seed, margin=1.0, wc=1.0):
+    """cVAE_multimodal_endtoend (cVAE.py:2021-2207), classifier in train() mode with dropout_rate = 0
+    (BatchNorm batch statistics; Dropout(0.5) masks are RNG-bound and excluded from parity)."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    M = len(dims)
+    model = ref.cVAE_multimodal_endtoend(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
+                                         modalities=M, non_linear=True, classifier_layers=list(layers), dropout_rate=0.0,
+                                         num_classes=2)
+    model.train()
+    out = {"meta": np.array([M, c_dim, Z, B, n_steps]), "dims": np.array(dims), "hidden": np.array(hidden),
+           "layers": np.array(layers), "margin_wc": np.array([margin, wc])}
+    out.update(sd_np(model, "w0:"))
+    xs = [torch.randn(n_steps, B, d, generator=g) for d in dims]
+    c = torch.stack([onehot_cov(g, B, c_dim) for _ in range(n_steps)])
+    labels = torch.randint(0, 2, (n_steps, B), generator=g)
+    eps = torch.randn(n_steps, B, Z, generator=g)
+    for m in range(M):
+        out[f"x{m}"] = xs[m].numpy()
+    out.update({"c": c.numpy(), "eps": eps.numpy(), "labels": labels.numpy()})
+    keys = ["total_loss", "recon_loss_health", "recon_loss_disease", "kl_loss", "classification_loss", "contrastive_loss"]
+    for s_ in range(n_steps):
+        xes = [xs[m][s_] for m in range(M)]
+        with fixed_eps([eps[s_]]):
+            fwd = model.forward(xes, [c[s_]] * M)
+        loss = model.loss_function(xes, fwd, labels[s_], margin, wc)
+        model.optimizer.zero_grad()
+        loss["total_loss"].backward()
+        if s_ == 0:
+            out["logits"] = fwd["logits"].detach().numpy().copy()
+            out["mu"] = fwd["mu"].detach().numpy().copy()
+            out["logvar"] = fwd["logvar"].detach().numpy().copy()
+            for m in range(M):
+                out[f"loc_h{m}"] = fwd["x_recons_health"][m].loc.detach().numpy().copy()
+                out[f"loc_d{m}"] = fwd["x_recons_disease"][m].loc.detach().numpy().copy()
+            out.update(grads_np(model, "g0:"))
+        out[f"loss{s_}"] = np.array([float(loss[k]) for k in keys])
+        model.optimizer.step()
+    out.update(sd_np(model, f"w{n_steps}:"))
+    model.eval()
+    out["predict"] = model.predict([xs[m][0] for m in range(M)], [c[0]] * M).numpy()
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name, out["loss0"])
+
+
 def case_csv_headers(name):
     """G7/G8: layout facts of the committed CSV artefacts (first line + IID column only, plus a
     known-answer slice of one (x, x_hat, err_roi, err) quintuple)."""
@@ -244,6 +326,8 @@ def main():
     case_single(ref, "single_small", 37, 7, (24, 16), 6, 19, seed=105)
     case_deviation(ref, "dev_small", (23, 17, 29), 5, (24, 16), 6, 40, "gpoe", seed=106)
     case_csv_headers("csv_layouts")
+    case_regression(ref, "reg3_gpoe", (23, 17, 29), 2, (24, 16), 6, 32, "gpoe", 3, seed=107)
+    case_endtoend(ref, "e2e3", (23, 17, 29), 7, (24, 16), 8, 32, (16, 8), 3, seed=108)
 
 
 if __name__ == "__main__":

@@ -113,3 +113,87 @@ def test_sweep_end_to_end_small():
             assert (df.iloc[:, 1:].to_numpy() >= 0).all()
     # the loss went down over training (first vs last logged step of the first job)
     assert rows[0, 3] < 6500
+
+
+def _traj_ok(sd, wref, lr, steps):
+    worst = 0.0
+    for k, v in wref.items():
+        if "running" in k or "num_batches" in k:
+            continue
+        worst = max(worst, float((sd[k] - v).abs().max()))
+    return worst <= 2.0 * lr * steps + 1e-6, worst
+
+
+def test_regression_model_matches_reference():
+    """cVAE_multimodal_regression (cVAE.py:2211-2346): trunk in the HIP kernel, regressor head through
+    d L / d x_hat; golden = the reference class itself."""
+    g = Golden("reg3_gpoe")
+    model = nm.cVAE_multimodal_regression(g.dims, g.hidden, g.Z, g.c_dim, learning_rate=1e-4, modalities=g.M, non_linear=True)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    for s in range(g.n_steps):
+        xes = [x.to(DEV) for x in g.xs(s)]
+        c = g.t("c")[s].to(DEV)
+        model._eps_override = g.t("eps")[s]
+        out = model.forward_multimodal(xes, [c] * g.M, g.combine)
+        losses = model.loss_function_multimodal(xes, out, g.t("fi")[s].to(DEV), lambda_reg=1.0)
+        ref = g.z[f"loss{s}"]                       # total, kl, ll, regression
+        assert abs(float(losses["ll"]) - ref[2]) <= 1e-4 * abs(ref[2]), s
+        assert abs(float(losses["regression"]) - ref[3]) <= 2e-2 * abs(ref[3]) + 1e-4, s
+        assert abs(float(losses["total"]) - ref[0]) <= 2e-4 * abs(ref[0]), s
+        if s == 0:
+            assert rel_err(out["fi_pred"].detach().cpu(), g.t("fi_pred")) < 3e-2
+            assert rel_err(out["x_recons"][1].loc.cpu(), g.t("loc1")) < 2e-2
+        model.optimizer1.zero_grad()
+        losses["total"].backward()
+        if s == 0:
+            gref = g.grads("g0")
+            got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+            for k in ("regressor.0.weight", "regressor.4.bias", "decoder_list.0.decoder_mean_layer.weight",
+                      "encoder_list.2.enc_mean_layer.weight", "decoder_list.1.decoder_layers.0.weight"):
+                a, r = got[k].flatten().float(), gref[k].flatten()
+                cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+                assert cos > 0.99, (k, cos)
+        model.optimizer1.step()
+    ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    assert ok, worst
+
+
+def test_endtoend_model_matches_reference():
+    """cVAE_multimodal_endtoend (cVAE.py:2021-2207), classifier in train() mode with dropout 0."""
+    g = Golden("e2e3")
+    layers = [int(v) for v in g.z["layers"]]
+    margin, wc = (float(v) for v in g.z["margin_wc"])
+    model = nm.cVAE_multimodal_endtoend(g.dims, g.hidden, g.Z, g.c_dim, modalities=g.M, non_linear=True,
+                                        classifier_layers=layers, dropout_rate=0.0, num_classes=2)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    model.train()
+    keys = ["total_loss", "recon_loss_health", "recon_loss_disease", "kl_loss", "classification_loss", "contrastive_loss"]
+    for s in range(g.n_steps):
+        xes = [x.to(DEV) for x in g.xs(s)]
+        c = g.t("c")[s].to(DEV)
+        labels = g.t("labels")[s].to(DEV)
+        model._eps_override = g.t("eps")[s]
+        fwd = model.forward(xes, [c] * g.M)
+        loss = model.loss_function(xes, fwd, labels, margin, wc)
+        ref = dict(zip(keys, g.z[f"loss{s}"]))
+        assert abs(float(loss["recon_loss_health"]) - ref["recon_loss_health"]) <= 1e-4 * ref["recon_loss_health"], s
+        assert abs(float(loss["recon_loss_disease"]) - ref["recon_loss_disease"]) <= 1e-4 * ref["recon_loss_disease"], s
+        assert abs(float(loss["kl_loss"]) - ref["kl_loss"]) <= 5e-3 * ref["kl_loss"], s
+        assert abs(float(loss["classification_loss"]) - ref["classification_loss"]) <= 2e-2 * ref["classification_loss"], s
+        assert abs(float(loss["contrastive_loss"]) - ref["contrastive_loss"]) <= 2e-2 * ref["contrastive_loss"] + 1e-3, s
+        assert abs(float(loss["total_loss"]) - ref["total_loss"]) <= 2e-3 * ref["total_loss"], s
+        if s == 0:
+            assert rel_err(fwd["mu"].cpu(), g.t("mu")) < 2e-2
+            assert rel_err(fwd["x_recons_disease"][2].loc.detach().cpu(), g.t("loc_d2")) < 2e-2
+            assert rel_err(fwd["logits"].detach().cpu(), g.t("logits")) < 5e-2
+        model.optimizer.zero_grad()
+        loss["total_loss"].backward()
+        model.optimizer.step()
+    ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    assert ok, worst
+    model.eval()
+    model._eps_override = None
+    logits = model.predict([x.to(DEV) for x in g.xs(0)], [g.t("c")[0].to(DEV)] * g.M)
+    assert rel_err(logits.cpu(), torch.from_numpy(g.z["predict"])) < 0.1
