@@ -690,6 +690,11 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
         vv[j] = *(const GAS f32x4*)(asg(J->adam_v) + pidx[j]);
       }
     }
+    // bias element of this thread (first nr threads): its p/m/v fly with the slab's groups
+    const bool bmine = has_bias && c.tid < nr;
+    const int64_t bidx = b_off + n0 + (bmine ? c.tid : 0);
+    float bp = 0.f, bm = 0.f, bv = 0.f;
+    if (do_adam && bmine) { bp = asg(J->params)[bidx]; bm = asg(J->adam_m)[bidx]; bv = asg(J->adam_v)[bidx]; }
     tr(c, 26);
     // ---- tiles -> slab: a unit is one k tile x two n tiles (the k-side fragment is shared) ----
     const int npairs = (nts + 1) / 2;
@@ -756,7 +761,14 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
         }
       }
     }
-    if (has_bias && c.tid < nr) apply_grad(c, b_off + n0 + c.tid, c.stage[c.tid * SP + (K - k_base)]);
+    if (bmine) {
+      const float bg = c.stage[c.tid * SP + (K - k_base)];
+      if (c.flags & NM_F_GRADS) asg(J->grads)[bidx] = bg;
+      if (do_adam) {
+        adam1(ak, bg, bp, bm, bv);
+        asg(J->params)[bidx] = bp; asg(J->adam_m)[bidx] = bm; asg(J->adam_v)[bidx] = bv;
+      }
+    }
     tr(c, 29);
     lds_barrier();
     tr(c, 30);
