@@ -26,9 +26,9 @@ def onehot(g, B, c_dim=29):
     return c
 
 
-def run_case(dims, Z, combine, B, seed, hidden=(110, 110), c_dim=29):
+def run_case(dims, Z, combine, B, seed, hidden=(110, 110), c_dim=29, non_linear=True):
     g = torch.Generator().manual_seed(seed)
-    spec = nm.ModelSpec(list(dims), list(hidden), Z, c_dim)
+    spec = nm.ModelSpec(list(dims), list(hidden), Z, c_dim, non_linear)
     lay = nm.ParamLayout(spec)
     P = lay.init_reference_rule(seed)
     xs = [torch.randn(B, d, generator=g) * 1.2 for d in dims]
@@ -39,7 +39,7 @@ def run_case(dims, Z, combine, B, seed, hidden=(110, 110), c_dim=29):
     job.enable_exports(sqerr=False, rowdev=False)
     nm.JobSet([job]).grads(0)
     torch.cuda.synchronize()
-    rs = R.Spec(list(dims), list(hidden), Z, c_dim)
+    rs = R.Spec(list(dims), list(hidden), Z, c_dim, non_linear)
     res = {}
     for mode in ("fp32", "bf16"):
         R.set_operand_rounding(mode)
@@ -91,6 +91,15 @@ def test_config4_early_fusion_1137_and_uca4():
 def test_config5_trunk_latent64_poe_ragged():
     # end-to-end model's trunk shape: Z = 64, three experts; ragged 83-row tail of the real HCPimage size
     run_case([379, 379, 379], 64, "poe", 83, seed=15)
+
+
+def test_shape_limits_and_variants():
+    """Kernel limits and less common variants: three hidden layers, the maximum hidden width (127) with the
+    maximum latent (64), one hidden layer, linear (non_linear=False) stacks, an odd ROI count."""
+    run_case([50, 61], 12, "mopoe", 100, seed=31, hidden=(64, 48, 32), c_dim=5)
+    run_case([77], 64, "poe", 130, seed=32, hidden=(127,), c_dim=29)
+    run_case([33, 45, 29], 7, "moe", 64, seed=33, hidden=(40, 24), c_dim=3, non_linear=False)
+    run_case([129], 5, "gpoe", 257 - 1, seed=34, hidden=(16, 127, 8), c_dim=3)
 
 
 def test_properties_full_size():
