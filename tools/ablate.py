@@ -10,10 +10,11 @@ from multi_modal_normative_modeling_amd import prep, workload, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--procedure", default="SM-T1w_sMRI")
 ap.add_argument("--steps", type=int, default=32)
+ap.add_argument("--xcd", action="store_true")
 a = ap.parse_args()
 cohort = prep.synthetic_cohort(n=1280, d=379)
-for nj in (1, 64, 256, 512):
-    jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, nj, "cuda:0")
+for nj in (256,):
+    jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, nj, "cuda:0", xcd_affinity=a.xcd)
     js = nm.JobSet(jobs)
     out = []
     for name, flags in (("fwd", 0), ("fwd+bwd", _lib.NM_F_BACKWARD), ("fwd+bwd+adam", _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)):
