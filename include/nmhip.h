@@ -110,6 +110,13 @@ typedef struct nm_job {
   float*  out_logvar;     /* NM_F_EXPORT: [rows_alloc][Z] joint logvar  (may be NULL)    */
   float*  out_z;          /* NM_F_EXPORT: [rows_alloc][Z] sampled z     (may be NULL)    */
   const float* dz_extra;  /* optional d L_extra / d z, [rows_alloc][Z] (classifier head, cVAE.py:2117) */
+  /* regressor of cVAE_multimodal_regression (cVAE.py:2249-2253): Linear(sum D, 128) - ReLU -
+   * Linear(128, 64) - ReLU - Linear(64, 1) on cat_m(x_m - x_hat_m); used by nm_head_regression only */
+  int32_t reg_head;       /* 1: reg_w / reg_b are valid                                  */
+  float   reg_lambda;     /* d total / d MSE  (lambda_reg, cVAE.py:2330-2346)            */
+  int64_t reg_w[3], reg_b[3];   /* regressor.{0,2,4}.weight / .bias offsets in params   */
+  const float* fi_target; /* [rows_alloc] regression target (may be NULL for forward)   */
+  float*  out_fi_pred;    /* [rows_alloc] prediction                                     */
   nm_modality_t mod[NM_MAX_MOD];
 } nm_job_t;
 
@@ -119,6 +126,7 @@ typedef struct nm_job {
 #define NM_LOSS_KL    1
 #define NM_LOSS_LL    2
 #define NM_LOSS_LL_M  3
+#define NM_LOSS_REG   12   /* MSE of the regression head (nm_head_regression) */
 
 /* Bytes of workspace one tile of a job needs (host-side helper, no device access). */
 int64_t nm_workspace_bytes(const nm_job_t* job_host);
@@ -139,6 +147,14 @@ int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_til
 int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream);
 int nm_grads(const nm_job_t* jobs_dev, int n_jobs, int step, void* stream);
 int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream);
+
+/* Regression head of cVAE_multimodal_regression (cVAE.py:2309-2346) on the exported reconstructions:
+ * one workgroup per (job, 256-row tile).  Reads mod[m].x_f32 and mod[m].out_loc (filled by a preceding
+ * NM_F_EXPORT launch), writes out_fi_pred and loss_log[.][NM_LOSS_REG] (row `step` mod loss_cap).  With
+ * NM_F_BACKWARD (needs fi_target) it also writes d(lambda * MSE)/d x_hat into mod[m].dloc_extra -- the
+ * next nm_launch(NM_F_BACKWARD) adds it to the ELBO gradient -- and the regressor's own gradients
+ * (NM_F_GRADS -> job.grads) or Adam update (NM_F_ADAM). */
+int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int n_tiles, int flags, void* stream);
 
 /* Stand-alone flat Adam (used by the eager API path).  t is the 1-based step count. */
 int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,

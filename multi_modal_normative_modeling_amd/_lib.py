@@ -26,6 +26,7 @@ NM_F_EXPORT = 8
 NM_F_PROFILE = 16
 NM_F_ZGIVEN = 32
 NM_F_TRACE = 64
+NM_LOSS_REG = 12
 
 LIB_NAME = "libnmhip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
@@ -59,6 +60,8 @@ class NmJob(C.Structure):
         ("eps", C.c_void_p), ("seed", C.c_uint64),
         ("loss_log", C.c_void_p), ("workspace", C.c_void_p), ("workspace_stride", C.c_int64),
         ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p), ("dz_extra", C.c_void_p),
+        ("reg_head", C.c_int32), ("reg_lambda", C.c_float), ("reg_w", C.c_int64 * 3), ("reg_b", C.c_int64 * 3),
+        ("fi_target", C.c_void_p), ("out_fi_pred", C.c_void_p),
         ("mod", NmModality * NM_MAX_MOD),
     ]
 
@@ -93,6 +96,7 @@ def load():
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_grads.argtypes = [vp, i32, i32, vp]
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
+    lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
     lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
@@ -110,7 +114,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read", "nm_trace_read",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression",
 ]
 
 

@@ -140,6 +140,10 @@ class _Base(nn.Module):
             self.alpha_m_list = nn.ParameterList([v[f"alpha_m_list.{m}"] for m in range(s.M)])
             self.encoder_list = nn.ModuleList([enc(m) for m in range(s.M)])
             self.decoder_list = nn.ModuleList([dec(m) for m in range(s.M)])
+        if s.kind == "regression":                # nn.Sequential(Linear, ReLU, Linear, ReLU, Linear), cVAE.py:2249-2253
+            self.regressor = nn.Module()
+            for i in (0, 2, 4):
+                self.regressor.add_module(str(i), _Holder(weight=v[f"regressor.{i}.weight"], bias=v[f"regressor.{i}.bias"]))
 
     def state_dict(self, *a, **k):
         return {n: t.detach().cpu().clone() for n, t in self._views().items()}
@@ -448,8 +452,25 @@ class _HeadBase(_Base):
         return [(n, p) for n, p in self.named_parameters() if n in self.layout.offsets]
 
 
+class _RegTotal(torch.autograd.Function):
+    """total = ELBO part + lambda * MSE; backward runs the head kernel (d MSE / d x_hat, regressor gradients)
+    and then the trunk launch that adds that extra gradient to the ELBO's."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, value):
+        ctx.model = model
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.model._backward_native(float(g))
+        return None, None, None
+
+
 class cVAE_multimodal_regression(_HeadBase):
-    """cVAE.py:2211-2346: cVAE_multimodal + a regressor on the concatenated residuals."""
+    """cVAE.py:2211-2346: cVAE_multimodal + a regressor on the concatenated residuals.  Trunk and regressor
+    both run in HIP (nm_launch + nm_head_regression); the regressor's tensors live in the same flat
+    parameter buffer under the reference's names regressor.{0,2,4}.{weight,bias}."""
 
     def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
                  non_linear=False):
@@ -459,42 +480,55 @@ class cVAE_multimodal_regression(_HeadBase):
         self.modalities, self.learning_rate, self.non_linear = modalities, learning_rate, non_linear
         self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "regression"),
                     learning_rate, kl_weight=float(modalities))
-        self.regressor = nn.Sequential(nn.Linear(sum(input_dim_list), 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
-                                       nn.Linear(64, 1))
         self.mse_loss = nn.MSELoss()
-        self.optimizer1 = _AdamWithHead(self, learning_rate, self.regressor.parameters())
-
-    def to(self, device):
-        super().to(device)
-        self.regressor.to(self._device)
-        self.optimizer1.head = torch.optim.Adam(self.regressor.parameters(), lr=self.learning_rate)
-        return self
-
-    def state_dict(self, *a, **k):
-        sd = super().state_dict()
-        sd.update({f"regressor.{n}": v.detach().cpu().clone() for n, v in self.regressor.state_dict().items()})
-        return sd
-
-    def load_state_dict(self, state, strict: bool = True):
-        super().load_state_dict({k: v for k, v in state.items() if not k.startswith("regressor.")})
-        self.regressor.load_state_dict({k[len("regressor."):]: v for k, v in state.items() if k.startswith("regressor.")})
-        return self
+        self.optimizer1 = _Adam(self, learning_rate)
 
     def forward_multimodal(self, xes, cs, combine):
+        if combine.lower() not in _lib.NM_COMBINE:
+            raise ValueError("No such combination method")
         eps = self._draw(int(xes[0].shape[0]))
-        j, B, locs, z = self._trunk_forward(xes, cs, combine, eps)
-        xs = [x.to(self._device, torch.float32) for x in xes]
-        recon_concat = torch.cat([xs[m] - locs[m] for m in range(self.modalities)], dim=1)     # cVAE.py:2318-2319
-        fi_pred = self.regressor(recon_concat)
-        self._last = (list(xes), list(cs), combine, eps, locs, z)
-        return {"x_recons": [NormalLike(locs[m].detach(), self._scale(m)) for m in range(self.modalities)],
-                "mu_multimodal": j.out_mu[:B].clone(), "logvar_multimodal": j.out_logvar[:B].clone(), "fi_pred": fi_pred}
+        j, B = self._run(xes, cs, combine, _lib.NM_F_EXPORT, eps=eps)
+        j.fi_target = None
+        j.touch()
+        JobSet([j]).head_regression(backward=False)                                     # cVAE.py:2318-2321
+        self._last = (list(xes), list(cs), combine, eps)
+        return {"x_recons": [NormalLike(j.out_loc[m][:B].clone(), self._scale(m)) for m in range(self.modalities)],
+                "mu_multimodal": j.out_mu[:B].clone(), "logvar_multimodal": j.out_logvar[:B].clone(),
+                "fi_pred": j.out_fi_pred[:B].clone().reshape(B, 1)}
 
     def loss_function_multimodal(self, xes, fwd_rtn, true_fi, lambda_reg=1.0):
-        row = self._job.loss_log[0]
-        reg = self.mse_loss(fwd_rtn["fi_pred"].squeeze(), true_fi.to(self._device).squeeze())
-        total = _HeadTrunkLoss.apply(self._anchor, self, row[0].clone(), [lambda_reg * reg])
+        j = self._job
+        row = j.loss_log[0]
+        fi = torch.as_tensor(true_fi, dtype=torch.float32).to(self._device).reshape(-1)
+        ra = j.tables[0].rows_alloc
+        j.fi_target = torch.zeros(ra, device=self._device)
+        j.fi_target[:fi.numel()] = fi
+        self._lambda = float(lambda_reg)
+        reg = self.mse_loss(fwd_rtn["fi_pred"].squeeze(), fi.squeeze())                 # cVAE.py:2340
+        total = _RegTotal.apply(self._anchor, self, row[0] + lambda_reg * reg)
         return {"total": total, "kl": row[1].clone(), "ll": row[2].clone().reshape(1), "regression": reg}
+
+    def _backward_native(self, g: float):
+        j = self._job
+        ra = j.tables[0].rows_alloc
+        for k, (m, _, _) in enumerate(j.kmods):
+            j.dloc_extra[k] = torch.zeros(ra, j.tables[m].x_pitch, device=self._device)
+        j.reg_lambda = self._lambda * g
+        j.kl_weight, j.ll_weight = self._kl_weight * g, g
+        j.step = 0
+        j.touch()
+        js = JobSet([j])
+        js.head_regression(backward=True, grads=True)                                   # head: d MSE/d x_hat + its grads
+        js._launch(0, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS)                       # trunk: ELBO + extra
+        j.dloc_extra = [None] * len(j.kmods)
+        j.kl_weight, j.ll_weight = self._kl_weight, 1.0
+        j.touch()
+        self._pending = j.grads
+        self._grads_ready = True
+        gv = self.layout.unflatten(self._pending)
+        for name, p in self._named_views():
+            if name in gv:
+                p.grad = gv[name]
 
     def encode(self, x, c, m):
         return cVAE_multimodal.encode(self, x, c, m)

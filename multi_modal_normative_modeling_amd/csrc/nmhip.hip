@@ -664,7 +664,7 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
   const int nkt = (ncols + 15) / 16;            // k tiles in this pass
   const int gpr = max(0, min(ncols, Kp - k_base)) >> 2;          // 16-byte parameter groups per row in this pass
   const float rg = gpr > 0 ? 1.0f / (float)gpr : 0.f;
-  const bool has_bias = (K >= k_base) && (K < k_base + ncols);
+  const bool has_bias = (b_off >= 0) && (K >= k_base) && (K < k_base + ncols);   // b_off < 0: no bias column in B
   const bool do_adam = (c.flags & NM_F_ADAM) != 0;
   const AdamK ak = adam_consts(c);
   constexpr int NG = 1024 / WG;                 // 16-byte parameter groups per thread and slab
@@ -1377,6 +1377,235 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   }
 }
 
+// ---- regression head (cVAE.py:2249-2253 regressor, 2318-2321 forward, 2330-2346 loss) ----------------
+// fi_pred = W3 relu(W2 relu(W1 cat_m(x_m - x_hat_m) + b1) + b2) + b3;  loss = mean_r (fi_pred - FI)^2.
+// One workgroup per (job, 256-row tile); same operand conventions as the trunk: bf16 MFMA operands,
+// fp32 accumulate, fp32 parameters.  The concatenated residual [256][sum D] is walked in 128-column
+// chunks of the CONCATENATED column space (so chunk boundaries stay 16-byte aligned inside W1's rows);
+// a chunk may straddle two modalities.
+struct CatCol { int m, d; };
+__device__ __forceinline__ CatCol cat_col(const nm_job_t* J, int M, int col) {
+  CatCol r{0, col};
+#pragma unroll
+  for (int m = 0; m < NM_MAX_EXP - 1; ++m) {
+    const int Dm = J->mod[m].D;
+    if (m < M - 1 && r.m == m && r.d >= Dm) { r.m = m + 1; r.d -= Dm; }
+  }
+  return r;
+}
+// Q[r][j] = x[r][col] - x_hat[r][col] for concatenated column col = k0 + j < SD, valid rows; 0 elsewhere
+__device__ __forceinline__ void resid_chunk_to_Q(const Ctx& c, int M, int SD, int k0) {
+  const nm_job_t* J = c.job;
+  const int j = c.tid & (PW - 1);               // WG is a multiple of PW: a thread keeps its column
+  const bool cv = k0 + j < SD;
+  const CatCol cc = cat_col(J, M, min(k0 + j, SD - 1));
+  const nm_modality_t& md = J->mod[cc.m];
+  gcf32 xf = asg(md.x_f32);
+  gcf32 xh = asg((const float*)md.out_loc);
+  for (int r = c.tid >> 7; r < ROWS; r += WG / PW) {
+    float v = xf[(int64_t)(c.row0 + r) * md.x_pitch + cc.d] - xh[(int64_t)(c.row0 + r) * md.D + cc.d];
+    c.Q[r * LDP + j] = (__bf16)((cv && r < c.nrows) ? v : 0.f);
+  }
+}
+// P[r][f] = relu(acc) for f < N (N a multiple of 16, <= 128)
+__device__ __forceinline__ void relu_to_P(const Ctx& c, const f32x4 (&acc)[2][RT], int N) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+    if (f0 >= N) continue;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int r = c.wm * WROWS + rt * 16 + c.c16;
+      bf16x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)fmaxf(acc[t][rt][i], 0.f);
+      *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restrict__ jobs, int step, int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const nm_job_t* J = jobs + blockIdx.x;
+  Ctx c;
+  c.job = J;
+  carve_lds(c, smem);
+  relaunder(c);
+  c.flags = flags & ~(NM_F_PROFILE | NM_F_TRACE);
+  c.t_last = 0;
+  c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
+  for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  __syncthreads();
+  c.row0 = blockIdx.y * ROWS;
+  c.nrows = min(ROWS, J->n_rows - c.row0);
+  if (c.nrows <= 0) return;
+  c.inv_b = 1.0f / (float)c.nrows;
+  const double tt = (double)(J->adam_off + (int64_t)step + 1);
+  c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
+  c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+  const bool bwd = (flags & NM_F_BACKWARD) != 0;
+  const int M = experts(J);
+  int SD = 0;
+  for (int m = 0; m < M; ++m) SD += J->mod[m].D;
+  constexpr int N1 = 128, N2 = 64;
+  gcf32 prm = asg(J->params);
+  gcf32 W1 = prm + J->reg_w[0], b1 = prm + J->reg_b[0], W2 = prm + J->reg_w[1], b2 = prm + J->reg_b[1];
+  gcf32 W3 = prm + J->reg_w[2];
+  const WsLayout wl = ws_layout(J->M, J->L, J->Z);
+  gbf16 ws_h1 = (gbf16)(c.ws + wl.zc);          // the trunk's workspace is dead between its two launches
+  const int nch = (SD + PW - 1) / PW;
+
+  // ---- layer 1: h1 = relu(W1 resid + b1), the residual streamed through Q ----
+  f32x4 acc[2][RT];
+  bias_acc(c, acc, b1, N1, 0);
+  for (int ch = 0; ch < nch; ++ch) {
+    relaunder(c);
+    const int k0 = ch * PW, valid = min(PW, SD - k0), ksteps = rup(valid, 32) / 32;
+    resid_chunk_to_Q(c, M, SD, k0);
+    lds_barrier();
+    for (int ks = 0; ks < ksteps; ++ks) {
+      bf16x8 wf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wf[t] = w_frag(W1, N1, SD, (c.wn + 4 * t) * 16 + c.c16, k0 + ks * 32 + 8 * c.g);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        bf16x8 a = lds_frag(c.Q, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+      }
+    }
+    lds_barrier();
+  }
+  relu_to_P(c, acc, N1);
+  lds_barrier();
+  if (bwd) store_act(c, ws_h1, c.P, N1);
+  // ---- layer 2: h2 = relu(W2 h1 + b2), in place ----
+  relaunder(c);
+  bias_acc(c, acc, b2, N2, 0);
+  for (int ks = 0; ks < N1 / 32; ++ks) {
+    bf16x8 wf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wf[t] = w_frag(W2, N2, N1, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+    }
+  }
+  lds_barrier();
+  relu_to_P(c, acc, N2);
+  lds_barrier();
+  // ---- layer 3 + MSE: one row per thread ----
+  relaunder(c);
+  float pred = 0.f, err = 0.f;
+  if (c.tid < ROWS) {
+    float s = prm[J->reg_b[2]];
+    for (int n = 0; n < N2; ++n) s = fmaf((float)c.P[c.tid * LDP + n], (float)(__bf16)W3[n], s);
+    pred = s;
+    if (c.tid < c.nrows) {
+      if (J->out_fi_pred) asg(J->out_fi_pred)[c.row0 + c.tid] = pred;
+      if (J->fi_target) err = pred - asg(J->fi_target)[c.row0 + c.tid];
+    }
+  }
+  const float sse = block_sum(c, err * err);
+  if (c.tid == 0 && J->loss_log && J->fi_target && blockIdx.y == 0)
+    asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_REG] = sse * c.inv_b;
+  if (!bwd) return;
+
+  // ---- backward ----
+  // d pred (rowacc), dW3 / db3 from h2, then P <- delta h2 = d pred * W3 * relu'(h2) in place
+  if (c.tid < ROWS) c.rowacc[c.tid] = J->reg_lambda * 2.0f * err * c.inv_b;     // err = 0 on padded rows
+  __syncthreads();
+  float g3 = 0.f;
+  if (c.tid < N2) {
+    for (int r = 0; r < ROWS; ++r) g3 = fmaf(c.rowacc[r], (float)c.P[r * LDP + c.tid], g3);
+  } else if (c.tid == N2) {
+    for (int r = 0; r < ROWS; ++r) g3 += c.rowacc[r];
+  }
+  __syncthreads();
+  for (int e = c.tid; e < ROWS * N2; e += WG) {
+    const int r = e >> 6, n = e & 63;
+    const float h = (float)c.P[r * LDP + n];
+    c.P[r * LDP + n] = (__bf16)(h > 0.f ? c.rowacc[r] * (float)(__bf16)W3[n] : 0.f);
+  }
+  __syncthreads();                               // W3 fully read before its update
+  if (c.tid < N2) apply_grad(c, J->reg_w[2] + c.tid, g3);
+  else if (c.tid == N2) apply_grad(c, J->reg_b[2], g3);
+  if (c.tid < N2) {                              // db2 = column sums of delta h2
+    float g = 0.f;
+    for (int r = 0; r < ROWS; ++r) g += (float)c.P[r * LDP + c.tid];
+    apply_grad(c, J->reg_b[1] + c.tid, g);
+  }
+  // layer 2 backward: Q <- h1; delta h1 (pre-mask) = delta h2 W2; dW2 = delta h2^T h1
+  load_act(c, c.Q, ws_h1, N1);
+  lds_barrier();
+  zero_acc(acc);
+  dgrad_acc(c, acc, c.P, W2, N2, N1, N2 / 32, 0);
+  lds_barrier();                                 // W2 fully read before its update
+  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N2, N1, 0, N1, J->reg_w[1], -1);
+  relaunder(c);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {                  // P <- delta h1 = acc * relu'(h1)
+    const int k0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int r = c.wm * WROWS + rt * 16 + c.c16;
+      bf16x4 a = *reinterpret_cast<const bf16x4*>(c.Q + r * LDP + k0);
+      bf16x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(((float)a[i] > 0.f) ? acc[t][rt][i] : 0.f);
+      *reinterpret_cast<bf16x4*>(c.P + r * LDP + k0) = pk;
+    }
+  }
+  lds_barrier();
+  if (c.tid < N1) {                              // db1
+    float g = 0.f;
+    for (int r = 0; r < ROWS; ++r) g += (float)c.P[r * LDP + c.tid];
+    apply_grad(c, J->reg_b[0] + c.tid, g);
+  }
+  // layer 1 backward per chunk: d resid = delta h1 W1 (-> dloc_extra = -d resid), dW1 chunk = delta h1^T resid
+  for (int ch = 0; ch < nch; ++ch) {
+    relaunder(c);
+    const int k0 = ch * PW, valid = min(PW, SD - k0);
+    resid_chunk_to_Q(c, M, SD, k0);
+    lds_barrier();
+    zero_acc(acc);
+    for (int s = 0; s < N1 / 32; ++s) {
+      bf16x8 wf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wf[t] = w_frag_t(W1, N1, SD, s * 32 + 8 * c.g, k0 + (c.wn + 4 * t) * 16 + c.c16);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, s * 32 + 8 * c.g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = k0 + (c.wn + 4 * t) * 16 + 4 * c.g + i;
+        if (col < SD) {
+          const CatCol cc = cat_col(J, M, col);
+          const nm_modality_t& md = J->mod[cc.m];
+          if (md.dloc_extra) {
+            gf32 dst = asg((float*)md.dloc_extra);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              const int r = c.wm * WROWS + rt * 16 + c.c16;
+              if (r < c.nrows) dst[(int64_t)(c.row0 + r) * md.x_pitch + cc.d] = -acc[t][rt][i];
+            }
+          }
+        }
+      }
+    }
+    lds_barrier();                               // W1 chunk fully read before its update
+    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N1, SD, k0, rup(valid, 16), J->reg_w[0], -1);
+  }
+}
+
 // ---- stand-alone kernels ----------------------------------------------------------------------
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
@@ -1500,7 +1729,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 2; }
+int nm_version(void) { return 3; }
 
 /* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {
@@ -1546,6 +1775,7 @@ const char* nm_status_string(int status) {
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
     case -10: return "parameter tensor offsets must be multiples of 4 floats";
+    case -11: return "regression head: needs reg_w / reg_b offsets (multiples of 4) and every expert's out_loc export";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
   }
 }
@@ -1567,6 +1797,12 @@ int nm_validate_job(const nm_job_t* j) {
     for (int i = 0; i < j->L; ++i)
       if ((md.enc_w[i] | md.enc_b[i] | md.dec_w[i] | md.dec_b[i]) & 3) return -10;
     if ((md.mu_w | md.mu_b | md.lv_w | md.lv_b | md.logvar_out | md.out_w | md.out_b) & 3) return -10;
+  }
+  if (j->reg_head) {
+    for (int i = 0; i < 3; ++i)
+      if (j->reg_w[i] < 0 || j->reg_b[i] < 0 || ((j->reg_w[i] | j->reg_b[i]) & 3)) return -11;
+    for (int m = 0; m < (j->M_enc == 0 ? j->M : j->M_enc); ++m)
+      if (!j->mod[m].out_loc) return -11;
   }
   return 0;
 }
@@ -1604,6 +1840,16 @@ int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_til
 int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
                         void* stream) {
   return launch_impl(jobs_dev, n_jobs, step0, steps_per_tile, n_tiles, flags, stream, true);
+}
+
+int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int n_tiles, int flags, void* stream) {
+  if (!jobs_dev) return -1;
+  if (n_jobs < 1 || n_tiles < 1 || step < 0) return -8;
+  hipError_t e = hipFuncSetAttribute((const void*)nm_reghead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(nm_reghead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,
+                     flags);
+  return (int)hipGetLastError();
 }
 
 int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream) {

@@ -102,6 +102,9 @@ class Job:
         self.dz_extra: Optional[torch.Tensor] = None  # d L_extra / d z          [rows_alloc, Z]
         self.dloc_extra: List[Optional[torch.Tensor]] = [None] * len(self.kmods)   # d L_extra / d x_hat [rows_alloc, x_pitch]
         self.ll_weight = float(ll_weight)
+        self.reg_lambda = 1.0                         # regression head (kind == "regression")
+        self.fi_target: Optional[torch.Tensor] = None # [rows_alloc]
+        self.out_fi_pred: Optional[torch.Tensor] = None
         self.single_bypass = bool(single_bypass)
         self.seed = int(seed)
         self.t = 0                       # optimizer steps taken
@@ -161,6 +164,8 @@ class Job:
             self.out_mu = torch.zeros(ra, Z, device=self.device)
             self.out_logvar = torch.zeros(ra, Z, device=self.device)
             self.out_z = torch.zeros(ra, Z, device=self.device)
+        if self.spec.kind == "regression":
+            self.out_fi_pred = torch.zeros(ra, device=self.device)
         for j, (m, _, _) in enumerate(self.kmods):
             t = self.tables[m]
             self.out_loc[j] = torch.zeros(ra, t.D, device=self.device) if loc else None
@@ -192,6 +197,12 @@ class Job:
         j.out_logvar = self.out_logvar.data_ptr() if self.out_logvar is not None else None
         j.out_z = self.out_z.data_ptr() if self.out_z is not None else None
         j.dz_extra = self.dz_extra.data_ptr() if self.dz_extra is not None else None
+        self.layout.fill_head(j)
+        if any(o is None for o in self.out_loc[:s.M]):
+            j.reg_head = 0                            # the head reads the exported reconstructions
+        j.reg_lambda = self.reg_lambda
+        j.fi_target = self.fi_target.data_ptr() if self.fi_target is not None else None
+        j.out_fi_pred = self.out_fi_pred.data_ptr() if self.out_fi_pred is not None else None
         for k, (m, _, _) in enumerate(self.kmods):
             t = self.tables[m]
             md = j.mod[k]
@@ -277,6 +288,17 @@ class JobSet:
         """forward-only over row tiles (one workgroup per (job, 256-row tile)); fills the exports."""
         nt = self.jobs[0].tables[0].n_tiles if n_tiles is None else n_tiles
         self._launch(tile0, 1, nt, _lib.NM_F_EXPORT)
+
+    def head_regression(self, backward: bool, grads: bool = True, adam: bool = False, step: int = 0,
+                        n_tiles: int = 1):
+        """nm_head_regression on the reconstructions a preceding forward() / NM_F_EXPORT launch exported:
+        fills out_fi_pred and loss_log[..][NM_LOSS_REG]; with backward also dloc_extra and the regressor's
+        gradients / Adam update (cVAE.py:2309-2346)."""
+        ptr = self._upload(n_tiles)
+        flags = (_lib.NM_F_BACKWARD if backward else 0) | (_lib.NM_F_GRADS if grads and backward else 0) | \
+                (_lib.NM_F_ADAM if adam and backward else 0)
+        _lib.check(self.lib.nm_head_regression(ptr, len(self.jobs), int(step), int(n_tiles), int(flags),
+                                               _stream_ptr(self.device)), "nm_head_regression")
 
     def losses(self) -> torch.Tensor:
         """[n_jobs, loss_cap, 8] on the host."""

@@ -18,6 +18,7 @@ from . import _lib
 
 ALIGN = 4   # floats
 ROW_PITCH = 8   # floats: weight-matrix rows are padded to this multiple (kpitch() in nmhip.hip)
+REGRESSOR_WIDTHS = (128, 64, 1)   # cVAE.py:2249-2253
 
 
 @dataclass
@@ -111,13 +112,17 @@ def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
             enc(m)
         for m in range(spec.M):
             dec(m)
-    elif spec.kind == "regression":          # cVAE.py:2230-2253: encoder_list, decoder_list, alpha_m_list (+ regressor: torch side)
+    elif spec.kind == "regression":          # cVAE.py:2230-2253: encoder_list, decoder_list, alpha_m_list, regressor
         for m in range(spec.M):
             enc(m)
         for m in range(spec.M):
             dec(m)
         for m in range(spec.M):
             out.append((f"alpha_m_list.{m}", (1,)))
+        sizes = [sum(spec.input_dims)] + list(REGRESSOR_WIDTHS)
+        for i in range(len(REGRESSOR_WIDTHS)):             # nn.Sequential indices 0, 2, 4 (ReLU at 1, 3)
+            out.append((f"regressor.{2 * i}.weight", (sizes[i + 1], sizes[i])))
+            out.append((f"regressor.{2 * i}.bias", (sizes[i + 1],)))
     elif spec.kind == "endtoend":            # cVAE.py:2044-2054: encoder_list, decoder_list_health, decoder_list_disease (+ classifier)
         for m in range(spec.M):
             enc(m)
@@ -214,3 +219,13 @@ class ParamLayout:
         md.logvar_out = o[f"{dp}logvar_out"]
         md.out_w, md.out_b = o[f"{dp}decoder_mean_layer.weight"], o[f"{dp}decoder_mean_layer.bias"]
         md.alpha = o.get(f"alpha_m_list.{m}", -1) if has_enc else -1
+
+    def fill_head(self, job: "_lib.NmJob"):
+        """Offsets of the regression head's tensors (kind == "regression")."""
+        if self.spec.kind != "regression":
+            job.reg_head = 0
+            return
+        job.reg_head = 1
+        for i in range(3):
+            job.reg_w[i] = self.offsets[f"regressor.{2 * i}.weight"]
+            job.reg_b[i] = self.offsets[f"regressor.{2 * i}.bias"]

@@ -479,9 +479,9 @@ def forward_regression(P, spec: Spec, xes, cs, combine: str, eps):
     trunk = Spec(spec.input_dims, spec.hidden, spec.latent, spec.c_dim, spec.non_linear, kind="multimodal")
     fwd = forward_multimodal(P, trunk, xes, cs, combine, eps)
     diffs = torch.cat([xes[m] - fwd["locs"][m] for m in range(spec.M)], dim=1)
-    h = torch.relu(torch.nn.functional.linear(diffs, P["regressor.0.weight"], P["regressor.0.bias"]))
-    h = torch.relu(torch.nn.functional.linear(h, P["regressor.2.weight"], P["regressor.2.bias"]))
-    fwd["fi_pred"] = torch.nn.functional.linear(h, P["regressor.4.weight"], P["regressor.4.bias"])
+    h = torch.relu(linear(diffs, P["regressor.0.weight"], P["regressor.0.bias"]))
+    h = torch.relu(linear(h, P["regressor.2.weight"], P["regressor.2.bias"]))
+    fwd["fi_pred"] = linear(h, P["regressor.4.weight"], P["regressor.4.bias"])
     return fwd
 
 

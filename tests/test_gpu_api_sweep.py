@@ -125,8 +125,8 @@ def _traj_ok(sd, wref, lr, steps):
 
 
 def test_regression_model_matches_reference():
-    """cVAE_multimodal_regression (cVAE.py:2211-2346): trunk in the HIP kernel, regressor head through
-    d L / d x_hat; golden = the reference class itself."""
+    """cVAE_multimodal_regression (cVAE.py:2211-2346): trunk (nm_launch) and regressor head (nm_head_regression) both
+    in HIP, coupled through d L / d x_hat; golden = the reference class itself."""
     g = Golden("reg3_gpoe")
     model = nm.cVAE_multimodal_regression(g.dims, g.hidden, g.Z, g.c_dim, learning_rate=1e-4, modalities=g.M, non_linear=True)
     model.load_state_dict(g.weights("w0"))
@@ -149,7 +149,8 @@ def test_regression_model_matches_reference():
         if s == 0:
             gref = g.grads("g0")
             got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
-            for k in ("regressor.0.weight", "regressor.4.bias", "decoder_list.0.decoder_mean_layer.weight",
+            for k in ("regressor.0.weight", "regressor.0.bias", "regressor.2.weight", "regressor.2.bias", "regressor.4.weight",
+                      "regressor.4.bias", "decoder_list.0.decoder_mean_layer.weight", "decoder_list.2.decoder_mean_layer.bias",
                       "encoder_list.2.enc_mean_layer.weight", "decoder_list.1.decoder_layers.0.weight"):
                 a, r = got[k].flatten().float(), gref[k].flatten()
                 cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
@@ -157,6 +158,48 @@ def test_regression_model_matches_reference():
         model.optimizer1.step()
     ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
     assert ok, worst
+
+
+def test_regression_head_multichunk_vs_oracle():
+    """nm_head_regression at a size whose concatenated residual spans several 128-column chunks, two of
+    them straddling a modality boundary, ragged batch: prediction, MSE, every regressor gradient and the
+    trunk gradients that receive d MSE / d x_hat, against the oracle with the kernel's operand rounding."""
+    dims, hidden, Z, cdim, B = [150, 90, 131], [48, 32], 10, 2, 200
+    torch.manual_seed(5)
+    model = nm.cVAE_multimodal_regression(dims, hidden, Z, cdim, learning_rate=1e-4, modalities=3, non_linear=True)
+    model.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.rand(B, cdim, generator=g) * 2
+    fi = torch.randn(B, 1, generator=g) * 0.5 + 1.0
+    eps = torch.randn(B, Z, generator=g)
+    model._eps_override = eps
+    out = model.forward_multimodal([x.to(DEV) for x in xes], [c.to(DEV)] * 3, "gpoe")
+    losses = model.loss_function_multimodal(xes, out, fi.to(DEV), lambda_reg=0.7)
+    model.optimizer1.zero_grad()
+    losses["total"].backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+    spec = R.Spec(dims, hidden, Z, cdim, True, kind="regression")
+    P = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    R.set_operand_rounding("bf16")
+    try:
+        fwd = R.forward_regression(P, spec, xes, [c] * 3, "gpoe", eps)
+        lo = R.loss_regression(spec, xes, fwd, fi, lambda_reg=0.7)
+        lo["total"].backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    assert rel_err(out["fi_pred"].cpu(), fwd["fi_pred"].detach()) < 5e-3
+    assert abs(float(losses["regression"]) - float(lo["regression"])) <= 5e-3 * float(lo["regression"])
+    assert abs(float(losses["total"]) - float(lo["total"])) <= 1e-4 * abs(float(lo["total"]))
+    for k, v in P.items():
+        a, r = got[k].flatten().float(), v.grad.flatten()
+        if float(r.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+        rl2 = float((a - r).norm() / r.norm())
+        assert cos > 0.995 and rl2 < 0.08, (k, cos, rl2)
 
 
 def test_endtoend_model_matches_reference():
