@@ -156,6 +156,22 @@ int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, voi
  * (NM_F_GRADS -> job.grads) or Adam update (NM_F_ADAM). */
 int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int n_tiles, int flags, void* stream);
 
+/* ---- post-hoc metrics of the sweep on the device ------------------------------------
+ * Sets are segments [offsets[s], offsets[s+1]) of the concatenated arrays; one workgroup per set, at most
+ * NM_METRICS_MAX_N scores per set.  out is [n_sets][NM_METRICS_STRIDE] fp64. */
+#define NM_METRICS_MAX_N  8192
+#define NM_METRICS_STRIDE 8
+/* compute_classification_performance(method='roc'), multimodal_kfold_cvae_group_analysis_1x1.py:105-157
+ * (sklearn roc_curve + auc, Youden-J threshold, then the confusion counts at that threshold):
+ * out = {roc_auc, threshold, accuracy, recall, specificity, significance_ratio, n_pos, n_neg}.
+ * labels != 0 is the positive class; thr_in (may be NULL) = the `optimal_threshold` argument per set. */
+int nm_posthoc_metrics(const float* scores, const int32_t* labels, const int32_t* offsets, int n_sets, int max_set,
+                       const double* thr_in, double* out, void* stream);
+/* evaluate(), multimodal_kfold_cvae_nmpmcont.py:29-70, from hard predictions:
+ * out = {accuracy, auroc, sensitivity, specificity, f1_score, precision, n_pos, n_neg}. */
+int nm_confusion_metrics(const int32_t* pred, const int32_t* labels, const int32_t* offsets, int n_sets, double* out,
+                         void* stream);
+
 /* Stand-alone flat Adam (used by the eager API path).  t is the 1-based step count. */
 int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
                  float lr, float beta1, float beta2, float eps, int64_t t, void* stream);

@@ -27,6 +27,8 @@ NM_F_PROFILE = 16
 NM_F_ZGIVEN = 32
 NM_F_TRACE = 64
 NM_LOSS_REG = 12
+NM_METRICS_MAX_N = 8192
+NM_METRICS_STRIDE = 8
 
 LIB_NAME = "libnmhip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
@@ -97,6 +99,8 @@ def load():
     lib.nm_grads.argtypes = [vp, i32, i32, vp]
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.nm_posthoc_metrics.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.nm_confusion_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
     lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
@@ -114,7 +118,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_posthoc_metrics", "nm_confusion_metrics",
 ]
 
 

@@ -1775,6 +1775,7 @@ const char* nm_status_string(int status) {
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
     case -10: return "parameter tensor offsets must be multiples of 4 floats";
+    case -12: return "metrics: n_sets >= 1 and 1 <= max_set <= NM_METRICS_MAX_N";
     case -11: return "regression head: needs reg_w / reg_b offsets (multiples of 4) and every expert's out_loc export";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
   }

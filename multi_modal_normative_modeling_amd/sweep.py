@@ -18,11 +18,14 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import io, prep, workload
+from . import io, metrics, prep, workload
 from .engine import Job, JobSet, Table
 from .layout import ModelSpec
 
-N_METRICS = 8          # job_id, fold, proc_id, final_total_loss, auc, mean_dev_hc, mean_dev_dx, steps_per_s
+# one row per cell in the table the final all_gather carries
+METRIC_COLUMNS = ("job_id", "fold", "proc_id", "final_total_loss", "steps_per_s", "roc_auc", "threshold", "accuracy",
+                  "sensitivity", "specificity", "mean_dev_hc", "mean_dev_dx")
+N_METRICS = len(METRIC_COLUMNS)
 
 
 @dataclass(frozen=True)
@@ -54,26 +57,6 @@ def assign(cells: Sequence[Cell], rank: int, world: int) -> List[Cell]:
     """Static round-robin by descending cost; ties keep job_id order."""
     order = sorted(cells, key=lambda c: (-c.cost, c.job_id))
     return order[rank::world]
-
-
-def roc_auc(scores: np.ndarray, positive: np.ndarray) -> float:
-    """Rank-based ROC-AUC (ties get mid-ranks), = sklearn.metrics.roc_auc_score."""
-    scores = np.asarray(scores, dtype=np.float64)
-    positive = np.asarray(positive, dtype=bool)
-    n1, n0 = int(positive.sum()), int((~positive).sum())
-    if n1 == 0 or n0 == 0:
-        return float("nan")
-    order = np.argsort(scores, kind="mergesort")
-    ranks = np.empty(len(scores), dtype=np.float64)
-    s = scores[order]
-    i = 0
-    while i < len(s):
-        j = i
-        while j + 1 < len(s) and s[j + 1] == s[i]:
-            j += 1
-        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
-        i = j + 1
-    return float((ranks[positive].sum() - n1 * (n1 + 1) / 2.0) / (n1 * n0))
 
 
 def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Tensor:
@@ -121,28 +104,36 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         total_steps += n * len(idxs)
     torch.cuda.synchronize(device)
     sps = total_steps / max(time.perf_counter() - t0, 1e-9)
-    rows = []
+    # deviation pass per cell; the per-subject score (mean over modalities of the ROI-mean deviation) stays on
+    # the GPU and feeds the metrics kernel (group_analysis_1x1.py:105-157); the ROI-wise matrix goes to the
+    # host only when a CSV is asked for
+    scores, finals = [], []
+    dx = torch.as_tensor(cohort.dia == 0)
     for c, j in zip(cells, jobs):
         mods, _ = workload.procedure_modalities(c.procedure)
         last = (j.step - 1) % j.loss_cap
-        final_loss = float(j.loss_log[last, 0])
+        finals.append(float(j.loss_log[last, 0]))
         per_subject = []
         for m, name in enumerate(mods):
-            dev, iids = deviation_roiwise(j, m, cohort, name, device)
-            per_subject.append(dev.mean(axis=1))
+            dev, rowdev, iids = deviation_roiwise(j, m, cohort, name, device, want_matrix=out_dir is not None)
+            per_subject.append(rowdev)
             if out_dir is not None:
                 io.write_roiwise_csv(out_dir, c.fold, name if c.replica == 0 else f"{name}_r{c.replica}", iids, dev)
-        score = np.mean(per_subject, axis=0)
-        dx = cohort.dia == 0
-        rows.append([c.job_id, c.fold, c.proc_id, final_loss, roc_auc(score, dx), float(score[~dx].mean()),
-                     float(score[dx].mean()), sps])
+        scores.append(torch.stack(per_subject).mean(dim=0))
+    pm = metrics.posthoc_metrics(scores, [dx] * len(cells), device=device).cpu()
+    rows = []
+    for i, c in enumerate(cells):
+        sc = scores[i].cpu()
+        rows.append([c.job_id, c.fold, c.proc_id, finals[i], sps, float(pm[i, 0]), float(pm[i, 1]), float(pm[i, 2]),
+                     float(pm[i, 3]), float(pm[i, 4]), float(sc[~dx].mean()), float(sc[dx].mean())])
     return torch.tensor(rows, dtype=torch.float32)
 
 
-def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str, device):
+def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str, device, want_matrix: bool = True):
     """ROI-wise deviation of ALL subjects through modality m's own encoder/decoder with a sampled z
     and a scaler re-fit on all subjects -- exactly the pass of
-    multimodal_kfold_train_cvae_supervised_regression.py:163-192."""
+    multimodal_kfold_train_cvae_supervised_regression.py:163-192.  Returns (ROI-wise matrix on the host or
+    None, per-subject ROI-mean deviation on the device, IIDs)."""
     src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
     center, scale = prep.robust_scaler_fit(src.astype(np.float32))
     x = prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32)
@@ -153,7 +144,8 @@ def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str,
     st = {k: sd[k.replace("_list.0.", f"_list.{m}.")] for k in ParamLayout(spec1).names}
     table = Table(x, c, device)
     one = Job(spec1, [table], combine="poe", state=st, seed=job.seed + 7919 * (m + 1), n_tiles_ws=table.n_tiles)
-    one.enable_exports(loc=False, sqerr=True, rowdev=False, latent=False)
+    one.enable_exports(loc=False, sqerr=want_matrix, rowdev=True, latent=False)
     JobSet([one]).forward()
     torch.cuda.synchronize(device)
-    return one.out_sqerr[0][: table.N].cpu().numpy(), cohort.iid
+    dev = one.out_sqerr[0][: table.N].cpu().numpy() if want_matrix else None
+    return dev, one.out_rowdev[0][: table.N].clone(), cohort.iid

@@ -105,6 +105,9 @@ def test_sweep_end_to_end_small():
         rows = sweep.run_cells(cohort, cells, 5, epochs=30, device=DEV, out_dir=d)
         assert rows.shape == (2, sweep.N_METRICS)
         assert torch.isfinite(rows).all()
+        col = {n: i for i, n in enumerate(sweep.METRIC_COLUMNS)}
+        assert ((rows[:, col["roc_auc"]] >= 0) & (rows[:, col["roc_auc"]] <= 1)).all()
+        assert ((rows[:, col["accuracy"]] > 0.5) & (rows[:, col["sensitivity"]] <= 1)).all()
         for c in cells:
             name = sweep.workload.procedure_modalities(c.procedure)[0][0]
             df = pd.read_csv(f"{d}/deviation_fold_{c.fold}_{name}_roiwise.csv")
@@ -240,3 +243,76 @@ def test_endtoend_model_matches_reference():
     model._eps_override = None
     logits = model.predict([x.to(DEV) for x in g.xs(0)], [g.t("c")[0].to(DEV)] * g.M)
     assert rel_err(logits.cpu(), torch.from_numpy(g.z["predict"])) < 0.1
+
+
+def _metric_sets():
+    rng = np.random.default_rng(3)
+    sets = []
+    for n, kind in [(213, "normal"), (213, "ties"), (64, "anti"), (17, "coarse"), (1064, "normal"), (5, "ties"),
+                    (300, "constant"), (2, "normal"), (257, "mixed"), (8192, "ties"), (4097, "normal"), (50, "oneclass")]:
+        lab = (rng.random(n) < 0.3).astype(np.int32)
+        lab[0], lab[-1] = 1, 0
+        if kind == "normal":
+            s = rng.normal(size=n) + 0.8 * lab
+        elif kind == "ties":
+            s = np.round(rng.normal(size=n) + 0.8 * lab, 1)
+        elif kind == "anti":
+            s = rng.normal(size=n) - 1.5 * lab
+        elif kind == "coarse":
+            s = rng.integers(0, 4, size=n).astype(float)
+        elif kind == "constant":
+            s = np.full(n, 0.25)
+        elif kind == "oneclass":
+            s, lab = rng.normal(size=n), np.zeros(n, dtype=np.int32)
+        else:
+            s = np.where(rng.random(n) < 0.5, np.round(rng.normal(size=n), 0), rng.normal(size=n)) + 0.5 * lab
+        sets.append((s.astype(np.float32), lab))
+    return sets
+
+
+def test_posthoc_metrics_kernel_vs_oracle():
+    """nm_posthoc_metrics against the sklearn-pinned oracle: threshold, counts-derived rates and
+    class sizes bit-exact, AUC within 1e-12 (the kernel divides the exact integer trapezoid sum once; numpy
+    sums float trapezoids); ties, constant scores, an anti-correlated set, one-class sets, 8192 = the maximum."""
+    from oracle import metrics_ref as MR
+    from multi_modal_normative_modeling_amd import metrics
+    sets = _metric_sets()
+    got = metrics.posthoc_metrics([torch.from_numpy(s) for s, _ in sets], [torch.from_numpy(l) for _, l in sets],
+                                  device=DEV).cpu().numpy()
+    for i, (s, lab) in enumerate(sets):
+        ref = MR.posthoc_metrics(s, lab)
+        if np.isnan(ref[0]):
+            assert np.isnan(got[i, :6]).all() and got[i, 6] == ref[6] and got[i, 7] == ref[7], i
+            continue
+        assert abs(got[i, 0] - ref[0]) < 1e-12, (i, got[i, 0], ref[0])
+        assert np.array_equal(got[i, 1:5], ref[1:5]), (i, got[i], ref)
+        assert abs(got[i, 5] - ref[5]) <= 1e-9 * abs(ref[5]) or (np.isinf(ref[5]) and np.isinf(got[i, 5])), i
+        assert got[i, 6] == ref[6] and got[i, 7] == ref[7]
+    # caller-supplied threshold (the `optimal_threshold` argument of the reference function)
+    thr = [0.3] * len(sets)
+    got2 = metrics.posthoc_metrics([torch.from_numpy(s) for s, _ in sets], [torch.from_numpy(l) for _, l in sets],
+                                   thresholds=thr, device=DEV).cpu().numpy()
+    for i, (s, lab) in enumerate(sets):
+        ref = MR.posthoc_metrics(s, lab, optimal_threshold=0.3)
+        if not np.isnan(ref[0]):
+            assert np.array_equal(got2[i, 1:5], ref[1:5]), (i, got2[i], ref)
+    with pytest.raises(ValueError):
+        metrics.posthoc_metrics([torch.zeros(8193)], [torch.zeros(8193)], device=DEV)
+
+
+def test_confusion_metrics_kernel_vs_oracle():
+    from oracle import metrics_ref as MR
+    from multi_modal_normative_modeling_amd import metrics
+    rng = np.random.default_rng(9)
+    preds, labs = [], []
+    for n in (150, 1, 4096, 33):
+        lab = (rng.random(n) < 0.4).astype(np.int32)
+        preds.append(np.where(rng.random(n) < 0.75, lab, 1 - lab).astype(np.int32))
+        labs.append(lab)
+    preds.append(np.zeros(40, dtype=np.int32)); labs.append((rng.random(40) < 0.5).astype(np.int32))
+    preds.append(np.ones(40, dtype=np.int32)); labs.append(np.ones(40, dtype=np.int32))
+    got = metrics.confusion_metrics([torch.from_numpy(p) for p in preds], [torch.from_numpy(l) for l in labs],
+                                    device=DEV).cpu().numpy()
+    for i in range(len(preds)):
+        ref = MR.confusion_metrics(preds[i], labs[i])
+        assert np.array_equal(got[i], ref, equal_nan=True), (i, got[i], ref)
