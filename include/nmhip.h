@@ -149,12 +149,15 @@ int nm_grads(const nm_job_t* jobs_dev, int n_jobs, int step, void* stream);
 int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream);
 
 /* Regression head of cVAE_multimodal_regression (cVAE.py:2309-2346) on the exported reconstructions:
- * one workgroup per (job, 256-row tile).  Reads mod[m].x_f32 and mod[m].out_loc (filled by a preceding
+ * one workgroup per (job, 256-row tile), tiles tile0 .. tile0 + n_tiles - 1 (training: the step's batch
+ * b = step mod ceil(n_rows/256), n_tiles = 1; inference: all tiles).  `step` selects the loss_log row and the
+ * Adam bias correction exactly as in nm_launch.  Reads mod[m].x_f32 and mod[m].out_loc (filled by a preceding
  * NM_F_EXPORT launch), writes out_fi_pred and loss_log[.][NM_LOSS_REG] (row `step` mod loss_cap).  With
  * NM_F_BACKWARD (needs fi_target) it also writes d(lambda * MSE)/d x_hat into mod[m].dloc_extra -- the
  * next nm_launch(NM_F_BACKWARD) adds it to the ELBO gradient -- and the regressor's own gradients
  * (NM_F_GRADS -> job.grads) or Adam update (NM_F_ADAM). */
-int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int n_tiles, int flags, void* stream);
+int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags,
+                       void* stream);
 
 /* ---- post-hoc metrics of the sweep on the device ------------------------------------
  * Sets are segments [offsets[s], offsets[s+1]) of the concatenated arrays; one workgroup per set, at most

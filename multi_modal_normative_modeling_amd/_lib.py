@@ -30,7 +30,7 @@ NM_LOSS_REG = 12
 NM_METRICS_MAX_N = 8192
 NM_METRICS_STRIDE = 8
 
-LIB_NAME = "libnmhip.so"
+LIB_NAME = os.environ.get("NMHIP_LIB_NAME", "libnmhip.so")     # diagnostic builds (tools/ablate.py) override the name
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 
 
@@ -98,7 +98,7 @@ def load():
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_grads.argtypes = [vp, i32, i32, vp]
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
-    lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_posthoc_metrics.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nm_confusion_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]

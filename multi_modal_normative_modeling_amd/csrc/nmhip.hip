@@ -1424,7 +1424,7 @@ __device__ __forceinline__ void relu_to_P(const Ctx& c, const f32x4 (&acc)[2][RT
   }
 }
 
-__global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restrict__ jobs, int step, int flags) {
+__global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const nm_job_t* J = jobs + blockIdx.x;
   Ctx c;
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
-  c.row0 = blockIdx.y * ROWS;
+  c.row0 = (tile0 + (int)blockIdx.y) * ROWS;
   c.nrows = min(ROWS, J->n_rows - c.row0);
   if (c.nrows <= 0) return;
   c.inv_b = 1.0f / (float)c.nrows;
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
     }
   }
   const float sse = block_sum(c, err * err);
-  if (c.tid == 0 && J->loss_log && J->fi_target && blockIdx.y == 0)
+  if (c.tid == 0 && J->loss_log && J->fi_target && blockIdx.y == 0)   // one tile's MSE (training: the step's batch)
     asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_REG] = sse * c.inv_b;
   if (!bwd) return;
 
@@ -1843,13 +1843,13 @@ int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int ste
   return launch_impl(jobs_dev, n_jobs, step0, steps_per_tile, n_tiles, flags, stream, true);
 }
 
-int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int n_tiles, int flags, void* stream) {
+int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags, void* stream) {
   if (!jobs_dev) return -1;
-  if (n_jobs < 1 || n_tiles < 1 || step < 0) return -8;
+  if (n_jobs < 1 || n_tiles < 1 || step < 0 || tile0 < 0) return -8;
   hipError_t e = hipFuncSetAttribute((const void*)nm_reghead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nm_reghead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,
-                     flags);
+                     tile0, flags);
   return (int)hipGetLastError();
 }
 

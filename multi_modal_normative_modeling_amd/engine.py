@@ -136,6 +136,25 @@ class Job:
         self._ws_tiles = n_tiles
         self._version += 1
 
+    def set_fi(self, fi):
+        """Regression target per table row (FI, ..._regression.py:86-87); padded with zeros to rows_alloc."""
+        ra = self.tables[0].rows_alloc
+        f = torch.as_tensor(fi, dtype=torch.float32).reshape(-1)
+        if f.numel() != self.tables[0].N:
+            raise ValueError(f"fi has {f.numel()} values for {self.tables[0].N} table rows")
+        self.fi_target = torch.zeros(ra, device=self.device)
+        self.fi_target[: f.numel()] = f.to(self.device)
+        self._version += 1
+
+    def prepare_regression(self):
+        """Buffers the regression train loop needs: exported reconstructions and the d MSE / d x_hat slots."""
+        if any(o is None for o in self.out_loc) or self.out_fi_pred is None:
+            self.enable_exports(loc=True, sqerr=False, rowdev=False, latent=False)
+        if any(d is None for d in self.dloc_extra):
+            ra = self.tables[0].rows_alloc
+            self.dloc_extra = [torch.zeros(ra, self.tables[m].x_pitch, device=self.device) for m, _, _ in self.kmods]
+            self._version += 1
+
     def touch(self):
         """Call after changing tables / step / t / hyper-parameters by hand: forces a descriptor re-upload."""
         self._version += 1
@@ -289,16 +308,40 @@ class JobSet:
         nt = self.jobs[0].tables[0].n_tiles if n_tiles is None else n_tiles
         self._launch(tile0, 1, nt, _lib.NM_F_EXPORT)
 
-    def head_regression(self, backward: bool, grads: bool = True, adam: bool = False, step: int = 0,
+    def head_regression(self, backward: bool, grads: bool = True, adam: bool = False, step: int = 0, tile0: int = 0,
                         n_tiles: int = 1):
         """nm_head_regression on the reconstructions a preceding forward() / NM_F_EXPORT launch exported:
         fills out_fi_pred and loss_log[..][NM_LOSS_REG]; with backward also dloc_extra and the regressor's
         gradients / Adam update (cVAE.py:2309-2346)."""
-        ptr = self._upload(n_tiles)
+        ptr = self._upload(max(n_tiles, 1))
         flags = (_lib.NM_F_BACKWARD if backward else 0) | (_lib.NM_F_GRADS if grads and backward else 0) | \
                 (_lib.NM_F_ADAM if adam and backward else 0)
-        _lib.check(self.lib.nm_head_regression(ptr, len(self.jobs), int(step), int(n_tiles), int(flags),
+        _lib.check(self.lib.nm_head_regression(ptr, len(self.jobs), int(step), int(tile0), int(n_tiles), int(flags),
                                                _stream_ptr(self.device)), "nm_head_regression")
+
+    def train_regression(self, n_steps: int):
+        """n_steps train steps of cVAE_multimodal_regression jobs, everything on the device, no host sync
+        (the loop of multimodal_kfold_train_cvae_supervised_regression.py:112-125): per step (i) forward with
+        the reconstructions exported, (ii) the regressor: forward, MSE, backward, its Adam update, d MSE / d x_hat,
+        (iii) the trunk's fused forward + ELBO + backward + Adam with that extra gradient.  (i) and (iii) draw the
+        same eps (counter-based generator keyed by the step, or the same block of job.eps)."""
+        step0 = self.jobs[0].step
+        for j in self.jobs:
+            if j.spec.kind != "regression" or j.fi_target is None:
+                raise ValueError("train_regression needs regression jobs with fi_target set")
+            if j.step != step0:
+                raise ValueError("jobs of one set must be at the same step")
+            j.prepare_regression()
+        nb = self.jobs[0].batches_per_epoch
+        if any(j.batches_per_epoch != nb for j in self.jobs):
+            raise ValueError("jobs of one set must have the same number of batches")
+        for s in range(step0, step0 + n_steps):
+            self._launch(s, 1, 1, _lib.NM_F_EXPORT)
+            self.head_regression(backward=True, grads=False, adam=True, step=s, tile0=s % nb)
+            self._launch(s, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)
+        for j in self.jobs:
+            j.step += n_steps
+            j.t += n_steps
 
     def losses(self) -> torch.Tensor:
         """[n_jobs, loss_cap, 8] on the host."""

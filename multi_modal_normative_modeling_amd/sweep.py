@@ -129,7 +129,8 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
     return torch.tensor(rows, dtype=torch.float32)
 
 
-def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str, device, want_matrix: bool = True):
+def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str, device, want_matrix: bool = True,
+                      covariates: Optional[np.ndarray] = None):
     """ROI-wise deviation of ALL subjects through modality m's own encoder/decoder with a sampled z
     and a scaler re-fit on all subjects -- exactly the pass of
     multimodal_kfold_train_cvae_supervised_regression.py:163-192.  Returns (ROI-wise matrix on the host or
@@ -137,7 +138,7 @@ def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str,
     src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
     center, scale = prep.robust_scaler_fit(src.astype(np.float32))
     x = prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32)
-    c = prep.one_hot_covariates(cohort.age, cohort.gender)
+    c = prep.one_hot_covariates(cohort.age, cohort.gender) if covariates is None else covariates
     spec1 = ModelSpec([job.spec.input_dims[m]], list(job.spec.hidden), job.spec.latent, job.spec.c_dim)
     sd = job.state_dict()
     from .layout import ParamLayout
@@ -149,3 +150,78 @@ def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str,
     torch.cuda.synchronize(device)
     dev = one.out_sqerr[0][: table.N].cpu().numpy() if want_matrix else None
     return dev, one.out_rowdev[0][: table.N].clone(), cohort.iid
+
+
+def evaluate_regression(y_true: np.ndarray, y_pred: np.ndarray) -> Dict[str, float]:
+    """RMSE / MAE / R2 / MAPE exactly as evaluate_regression of
+    multimodal_kfold_train_cvae_supervised_regression.py:30-35 forms them."""
+    y_true = np.asarray(y_true, dtype=np.float64).reshape(-1)
+    y_pred = np.asarray(y_pred, dtype=np.float64).reshape(-1)
+    err = y_true - y_pred
+    ss_res, ss_tot = float((err ** 2).sum()), float(((y_true - y_true.mean()) ** 2).sum())
+    return {"RMSE": float(np.sqrt((err ** 2).mean())), "MAE": float(np.abs(err).mean()),
+            "R2": 1.0 - ss_res / ss_tot if ss_tot > 0 else float("nan"),
+            "MAPE": float(np.mean(np.abs(err / (y_true + 1e-6))) * 100)}
+
+
+def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int], n_folds: int, epochs: int, device,
+                         out_dir=None, modalities: Sequence[str] = prep.HCP_MODALITIES, combine: str = "gpoe",
+                         lr: float = 1e-4, lambda_reg: float = 1.0):
+    """The whole of multimodal_kfold_train_cvae_supervised_regression.py:52-192 for the given folds, all folds
+    training concurrently: cVAE_multimodal_regression on RobustScaler-ed ROI tables with the two raw covariates
+    (AGE, PTGENDER) and the FI target; FI prediction on the held-out fold (fold_{k}_pred.npy / _true.npy and
+    RMSE / MAE / R2 / MAPE); ROI-wise deviation of every subject per modality
+    (deviation_fold_{k}_{name}_roiwise.csv).  Deviation from the script: batches are taken in table order and
+    aligned across modalities (its three independently shuffled DataLoaders pair different subjects, :94)."""
+    folds = prep.kfold_indices(len(cohort.iid), n_folds, 42)
+    cov_all = np.stack([cohort.age, cohort.gender], axis=1).astype(np.float32)
+    jobs, scalers = [], []
+    for k in folds_to_run:
+        tr = folds[k][0]
+        xs, sc = [], []
+        for m in modalities:
+            center, scale = prep.robust_scaler_fit(cohort.x[m][tr])
+            xs.append(prep.robust_scaler_transform(cohort.x[m][tr], center, scale).astype(np.float32))
+            sc.append((center, scale))
+        scalers.append(sc)
+        tables = [Table(x, cov_all[tr], device) for x in xs]
+        spec = ModelSpec([t.D for t in tables], list(workload.HIDDEN), workload.LATENT, 2, True, "regression")
+        j = Job(spec, tables, combine=combine, lr=lr, seed=1000 * k, init_seed=42 + k, loss_cap=8)
+        j.reg_lambda = float(lambda_reg)
+        j.set_fi(cohort.fi[tr].astype(np.float32))
+        jobs.append(j)
+    js = JobSet(jobs)
+    n = epochs * jobs[0].batches_per_epoch
+    t0 = time.perf_counter()
+    js.train_regression(n)
+    torch.cuda.synchronize(device)
+    sps = n * len(jobs) / max(time.perf_counter() - t0, 1e-9)
+    results = []
+    for k, j, sc in zip(folds_to_run, jobs, scalers):
+        te = folds[k][1]
+        # held-out FI prediction (:127-149): joint posterior, sampled z
+        xs = [prep.robust_scaler_transform(cohort.x[m][te], *sc[i]).astype(np.float32) for i, m in enumerate(modalities)]
+        tables = [Table(x, cov_all[te], device) for x in xs]
+        ev = Job(j.spec, tables, combine=combine, state=j.state_dict(), seed=j.seed + 17, n_tiles_ws=tables[0].n_tiles)
+        ev.enable_exports(loc=True, sqerr=False, rowdev=False, latent=False)
+        es = JobSet([ev])
+        es.forward()
+        es.head_regression(backward=False, tile0=0, n_tiles=tables[0].n_tiles)
+        torch.cuda.synchronize(device)
+        pred = ev.out_fi_pred[: len(te)].cpu().numpy().reshape(-1, 1)
+        true = cohort.fi[te].astype(np.float32).reshape(-1, 1)
+        scores = evaluate_regression(true, pred)
+        if out_dir is not None:
+            out = Path(out_dir)
+            out.mkdir(parents=True, exist_ok=True)
+            np.save(out / f"fold_{k}_pred.npy", pred)
+            np.save(out / f"fold_{k}_true.npy", true)
+        # ROI-wise deviation of every subject, one modality at a time (:163-192)
+        for i, m in enumerate(modalities):
+            dev, _, iids = deviation_roiwise(j, i, cohort, m, device, want_matrix=out_dir is not None, covariates=cov_all)
+            if out_dir is not None:
+                io.write_roiwise_csv(out_dir, k, m, iids, dev)
+        last = (j.step - 1) % j.loss_cap
+        results.append({"fold": k, "steps_per_s": sps, "final_total": float(j.loss_log[last, 0]),
+                        "final_mse": float(j.loss_log[last, 12]), **scores})
+    return results

@@ -316,3 +316,62 @@ def test_confusion_metrics_kernel_vs_oracle():
     for i in range(len(preds)):
         ref = MR.confusion_metrics(preds[i], labs[i])
         assert np.array_equal(got[i], ref, equal_nan=True), (i, got[i], ref)
+
+
+def test_fused_regression_training_matches_reference_trajectory():
+    """JobSet.train_regression (three launches per step, Adam inside the kernels) against the reference class's
+    own 3-step trajectory (golden reg3_gpoe) and against the eager facade path (same kernels, gradients through
+    job.grads + flat Adam)."""
+    from tests.hip_harness import make_job, swap_batch
+    g = Golden("reg3_gpoe")
+    job = make_job(g, 0, kind="regression")
+    js = nm.JobSet([job])
+    for s in range(g.n_steps):
+        if s > 0:
+            swap_batch(job, g, s)
+        job.set_fi(g.t("fi")[s])
+        js.train_regression(1)
+        torch.cuda.synchronize()
+        ref = g.z[f"loss{s}"]                       # total, kl, ll, regression
+        row = job.loss_log[0].cpu()
+        assert abs(float(row[2]) - ref[2]) <= 1e-4 * abs(ref[2]), s
+        assert abs(float(row[12]) - ref[3]) <= 2e-2 * abs(ref[3]) + 1e-4, s
+    ok, worst = _traj_ok(job.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    assert ok, worst
+    # eager facade on the same data: same kernels, so the two trajectories agree far below one Adam step
+    model = nm.cVAE_multimodal_regression(g.dims, g.hidden, g.Z, g.c_dim, learning_rate=1e-4, modalities=g.M, non_linear=True)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    for s in range(g.n_steps):
+        xes = [x.to(DEV) for x in g.xs(s)]
+        c = g.t("c")[s].to(DEV)
+        model._eps_override = g.t("eps")[s]
+        out = model.forward_multimodal(xes, [c] * g.M, g.combine)
+        losses = model.loss_function_multimodal(xes, out, g.t("fi")[s].to(DEV), lambda_reg=1.0)
+        model.optimizer1.zero_grad()
+        losses["total"].backward()
+        model.optimizer1.step()
+    sd_f, sd_e = job.state_dict(), model.state_dict()
+    worst = max(float((sd_f[k] - sd_e[k]).abs().max()) for k in sd_f)
+    assert worst <= 2e-6, worst
+
+
+def test_regression_sweep_end_to_end_small():
+    """run_regression_folds = the whole regression script for two folds at once: the MSE falls, FI predictions and
+    ROI-wise deviation CSVs come out in the reference layout."""
+    cohort = prep.synthetic_cohort(n=320, d=116)
+    cohort.fi[:] = (cohort.fi - cohort.fi.mean()) / cohort.fi.std()        # unit-scale target: fast to fit
+    with tempfile.TemporaryDirectory() as d:
+        res0 = sweep.run_regression_folds(cohort, [0, 3], 5, epochs=1, device=DEV, out_dir=None)
+        res = sweep.run_regression_folds(cohort, [0, 3], 5, epochs=150, device=DEV, out_dir=d)
+        assert [r["fold"] for r in res] == [0, 3]
+        for r0, r in zip(res0, res):
+            assert np.isfinite([r["RMSE"], r["MAE"], r["R2"], r["MAPE"], r["final_total"]]).all()
+            assert r["final_mse"] < 0.7 * r0["final_mse"], (r0["final_mse"], r["final_mse"])
+        for k in (0, 3):
+            pred, true = np.load(f"{d}/fold_{k}_pred.npy"), np.load(f"{d}/fold_{k}_true.npy")
+            assert pred.shape == true.shape == (64, 1)
+            for name in prep.HCP_MODALITIES:
+                df = pd.read_csv(f"{d}/deviation_fold_{k}_{name}_roiwise.csv")
+                assert list(df.columns) == ["IID"] + [f"ROI_{i}" for i in range(116)]
+                assert (df["IID"].to_numpy() == cohort.iid).all() and (df.iloc[:, 1:].to_numpy() >= 0).all()

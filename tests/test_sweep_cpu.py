@@ -88,3 +88,16 @@ def test_metric_gather_gloo_world2():
     assert allm[:, 0].tolist() == list(range(9))                        # every cell once, ordered by job id
     assert torch.allclose(allm[:, 3], 100.0 + allm[:, 0])
     assert set(allm[:, 4].tolist()) == {10.0, 20.0}                     # rows really came from both ranks
+
+
+def test_evaluate_regression_matches_sklearn():
+    """sweep.evaluate_regression vs the sklearn calls of ..._regression.py:30-35."""
+    from sklearn.metrics import mean_squared_error, mean_absolute_error, r2_score
+    rng = np.random.default_rng(1)
+    t = rng.normal(100, 15, size=(64, 1)).astype(np.float32)
+    p = (t + rng.normal(0, 5, size=(64, 1))).astype(np.float32)
+    got = sweep.evaluate_regression(t, p)
+    assert abs(got["RMSE"] - np.sqrt(mean_squared_error(t, p))) < 1e-5
+    assert abs(got["MAE"] - mean_absolute_error(t, p)) < 1e-5
+    assert abs(got["R2"] - r2_score(t, p)) < 1e-6
+    assert abs(got["MAPE"] - np.mean(np.abs((t - p) / (t + 1e-6))) * 100) < 1e-4
