@@ -33,6 +33,8 @@ extern "C" {
 
 #define NM_MAX_MOD 8     /* decoders per model (SM: 1, SE: 3, UCA: 4, end-to-end: 2 banks x 3)   */
 #define NM_MAX_EXP 4     /* experts = modalities that also have an encoder                        */
+#define NM_MAX_CLS 3       /* hidden blocks of the end-to-end classifier */
+#define NM_MAX_CLASSES 4
 #define NM_MAX_HID 3     /* hidden layers per encoder / decoder stack            */
 #define NM_BATCH   256   /* rows per workgroup tile (= reference batch size)      */
 #define NM_MAX_WIDTH 127 /* max hidden width, and max latent + c_dim             */
@@ -49,7 +51,8 @@ enum {
   NM_F_EXPORT   = 8,   /* store mu / logvar / z / loc / squared residual per row      */
   NM_F_PROFILE  = 16,  /* workgroup (0,0) accumulates per-phase shader-clock cycles   */
   NM_F_ZGIVEN   = 32,  /* job.eps holds the latent z itself: decode(z, c, m), cVAE.py:1135 */
-  NM_F_TRACE    = 64   /* workgroup (0,0): per-wave interval timers between in-kernel stamps */
+  NM_F_TRACE    = 64,  /* workgroup (0,0): per-wave interval timers between in-kernel stamps */
+  NM_F_BNSTATS  = 256  /* nm_head_classifier: update BatchNorm running statistics (once per train-mode forward) */
 };
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the
@@ -74,6 +77,10 @@ typedef struct nm_modality {
   /* optional extra loss gradient on the reconstruction, d L_extra / d x_hat, [rows_alloc][x_pitch]
    * (regression head cVAE.py:2309-2346, contrastive hinge cVAE.py:2140-2200); added to the NLL term */
   const float* dloc_extra;
+  /* optional per-row coefficient of an extra loss that depends on x_hat only through the row's squared
+   * deviation: d L_extra / d x_hat[r][d] = dloc_rowcoef[r] * (x_hat - x)[r][d]  (contrastive hinge on
+   * compute_deviation, cVAE.py:2134-2138, 2178-2182), [rows_alloc] */
+  const float* dloc_rowcoef;
 } nm_modality_t;
 
 /* One independent model (a (fold, procedure) cell of the sweep). */
@@ -117,6 +124,24 @@ typedef struct nm_job {
   int64_t reg_w[3], reg_b[3];   /* regressor.{0,2,4}.weight / .bias offsets in params   */
   const float* fi_target; /* [rows_alloc] regression target (may be NULL for forward)   */
   float*  out_fi_pred;    /* [rows_alloc] prediction                                     */
+  /* Classifier of cVAE_multimodal_endtoend (cVAE.py:2004-2018): cls_layers blocks of Linear - BatchNorm1d -
+   * ReLU - Dropout, then Linear(., cls_classes); used by nm_head_classifier only */
+  int32_t cls_layers;     /* 0: no classifier; <= NM_MAX_CLS                             */
+  int32_t cls_classes;    /* <= NM_MAX_CLASSES                                           */
+  int32_t cls_width[NM_MAX_CLS];
+  int32_t cls_train;      /* 1: batch statistics + dropout (module.train()); 0: running statistics     */
+  int32_t cls_use_mu;     /* 1: classify the joint mean out_mu (predict, cVAE.py:2202-2207), 0: out_z    */
+  int64_t cls_w[NM_MAX_CLS + 1], cls_b[NM_MAX_CLS + 1];        /* Linear i; index cls_layers = output layer */
+  int64_t cls_bn_w[NM_MAX_CLS], cls_bn_b[NM_MAX_CLS];          /* BatchNorm1d weight / bias                 */
+  int64_t cls_bn_mean[NM_MAX_CLS], cls_bn_var[NM_MAX_CLS];     /* running_mean / running_var (in params)    */
+  float   cls_dropout;    /* drop probability (train mode)                               */
+  float   cls_margin;     /* contrastive margin                                          */
+  float   cls_w_ce;       /* d total / d cross-entropy   (1 in cVAE.py:2188)             */
+  float   cls_w_contrast; /* d total / d contrastive     (weightcontrastive)             */
+  const int32_t* labels;  /* [rows_alloc] class labels (may be NULL: forward / predict)  */
+  float*  out_logits;     /* [rows_alloc][NM_MAX_CLASSES]                                */
+  float*  dz_out;         /* [rows_alloc][Z]: receives d (CE) / d z; pass the same buffer as dz_extra */
+  float*  rowcoef_out[NM_MAX_MOD];  /* [rows_alloc] per decoder: receives dloc_rowcoef of the hinge (may be NULL) */
   nm_modality_t mod[NM_MAX_MOD];
 } nm_job_t;
 
@@ -127,6 +152,8 @@ typedef struct nm_job {
 #define NM_LOSS_LL    2
 #define NM_LOSS_LL_M  3
 #define NM_LOSS_REG   12   /* MSE of the regression head (nm_head_regression) */
+#define NM_LOSS_CE    13   /* cross entropy of the classifier head (nm_head_classifier) */
+#define NM_LOSS_CONTRAST 14 /* contrastive hinge of the classifier head */
 
 /* Bytes of workspace one tile of a job needs (host-side helper, no device access). */
 int64_t nm_workspace_bytes(const nm_job_t* job_host);
@@ -157,6 +184,15 @@ int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, voi
  * next nm_launch(NM_F_BACKWARD) adds it to the ELBO gradient -- and the regressor's own gradients
  * (NM_F_GRADS -> job.grads) or Adam update (NM_F_ADAM). */
 int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags,
+                       void* stream);
+
+/* Classifier head of cVAE_multimodal_endtoend on the exported latent and deviations (cVAE.py:2004-2018,
+ * 2117, 2140-2200): logits = classifier(z), cross entropy, and the contrastive hinge on the per-subject
+ * deviations (mod[k].out_rowdev of the health bank k < M_enc and the disease bank M_enc <= k < 2 M_enc).
+ * Writes out_logits, loss_log[.][NM_LOSS_CE / NM_LOSS_CONTRAST]; with NM_F_BACKWARD also dz_out, rowcoef_out
+ * and the classifier's gradients (NM_F_GRADS) or Adam update (NM_F_ADAM).  Tiles / step as in
+ * nm_head_regression; train-mode BatchNorm statistics are per tile (= per batch). */
+int nm_head_classifier(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags,
                        void* stream);
 
 /* ---- post-hoc metrics of the sweep on the device ------------------------------------

@@ -12,6 +12,8 @@ from pathlib import Path
 NM_MAX_MOD = 8
 NM_MAX_EXP = 4
 NM_MAX_HID = 3
+NM_MAX_CLS = 3
+NM_MAX_CLASSES = 4
 NM_BATCH = 256
 NM_MAX_WIDTH = 127
 NM_MAX_LATENT = 64
@@ -27,6 +29,9 @@ NM_F_PROFILE = 16
 NM_F_ZGIVEN = 32
 NM_F_TRACE = 64
 NM_LOSS_REG = 12
+NM_LOSS_CE = 13
+NM_LOSS_CONTRAST = 14
+NM_F_BNSTATS = 256
 NM_METRICS_MAX_N = 8192
 NM_METRICS_STRIDE = 8
 
@@ -45,7 +50,7 @@ class NmModality(C.Structure):
         ("out_w", C.c_int64), ("out_b", C.c_int64),
         ("alpha", C.c_int64),
         ("out_loc", C.c_void_p), ("out_sqerr", C.c_void_p), ("out_rowdev", C.c_void_p),
-        ("dloc_extra", C.c_void_p),
+        ("dloc_extra", C.c_void_p), ("dloc_rowcoef", C.c_void_p),
     ]
 
 
@@ -64,6 +69,14 @@ class NmJob(C.Structure):
         ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p), ("dz_extra", C.c_void_p),
         ("reg_head", C.c_int32), ("reg_lambda", C.c_float), ("reg_w", C.c_int64 * 3), ("reg_b", C.c_int64 * 3),
         ("fi_target", C.c_void_p), ("out_fi_pred", C.c_void_p),
+        ("cls_layers", C.c_int32), ("cls_classes", C.c_int32), ("cls_width", C.c_int32 * NM_MAX_CLS),
+        ("cls_train", C.c_int32), ("cls_use_mu", C.c_int32),
+        ("cls_w", C.c_int64 * (NM_MAX_CLS + 1)), ("cls_b", C.c_int64 * (NM_MAX_CLS + 1)),
+        ("cls_bn_w", C.c_int64 * NM_MAX_CLS), ("cls_bn_b", C.c_int64 * NM_MAX_CLS),
+        ("cls_bn_mean", C.c_int64 * NM_MAX_CLS), ("cls_bn_var", C.c_int64 * NM_MAX_CLS),
+        ("cls_dropout", C.c_float), ("cls_margin", C.c_float), ("cls_w_ce", C.c_float), ("cls_w_contrast", C.c_float),
+        ("labels", C.c_void_p), ("out_logits", C.c_void_p), ("dz_out", C.c_void_p),
+        ("rowcoef_out", C.c_void_p * NM_MAX_MOD),
         ("mod", NmModality * NM_MAX_MOD),
     ]
 
@@ -99,6 +112,7 @@ def load():
     lib.nm_grads.argtypes = [vp, i32, i32, vp]
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.nm_head_classifier.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_posthoc_metrics.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nm_confusion_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
@@ -118,7 +132,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_posthoc_metrics", "nm_confusion_metrics",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_posthoc_metrics", "nm_confusion_metrics",
 ]
 
 

@@ -367,86 +367,17 @@ class cVAE(_Base):
 # =========================================================================================================
 # Models with a head on top of the trunk: cVAE_multimodal_regression, cVAE_multimodal_endtoend
 # =========================================================================================================
-# The trunk (encoders, fusion, decoders, ELBO, their backward and Adam: all but 2-30 % of the parameters)
-# runs in the HIP kernel.  The heads depend on the trunk only through x_hat and z, so they enter the kernel
-# as extra loss gradients d L_head / d x_hat (nm_modality_t.dloc_extra) and d L_head / d z (nm_job_t.dz_extra):
-# launch A exports x_hat / z, the head (a few small dense layers, currently rocBLAS GEMMs through PyTorch-ROCm
-# with autograd) produces its loss and those two gradients, launch B runs the trunk's backward with them.
-
-
-class _HeadTrunkLoss(torch.autograd.Function):
-    """total = trunk part (from the kernel) + head part (torch graph).  backward: head first (fills the
-    gradients w.r.t. x_hat / z and the head's parameters), then the trunk launch with those as extras."""
-
-    @staticmethod
-    def forward(ctx, anchor, model, trunk_value, head_box):
-        # the head loss travels in a list: as a tensor argument autograd would chain its graph behind this
-        # node and run it a second time after the explicit backward below
-        ctx.model, ctx.head_loss = model, head_box[0]
-        return trunk_value + head_box[0].detach()
-
-    @staticmethod
-    def backward(ctx, g):
-        ctx.model._backward_with_head(ctx.head_loss, g)
-        return None, None, None, None
-
-
-class _AdamWithHead(_Adam):
-    def __init__(self, model, lr, head_params):
-        super().__init__(model, lr)
-        self.head = torch.optim.Adam(list(head_params), lr=lr)
-
-    def zero_grad(self, set_to_none: bool = True):
-        super().zero_grad()
-        self.head.zero_grad(set_to_none=set_to_none)
-
-    def step(self):
-        super().step()
-        self.head.step()
+# The trunk (encoders, fusion, decoders, ELBO, their backward and Adam) is the step kernel; the heads are their
+# own HIP kernels (nm_head_regression, nm_head_classifier).  They depend on the trunk only through x_hat, z and
+# the per-subject deviations, so they hand back extra loss gradients (nm_modality_t.dloc_extra / dloc_rowcoef,
+# nm_job_t.dz_extra) that the trunk's backward launch adds to the ELBO's.
 
 
 class _HeadBase(_Base):
-    def _trunk_forward(self, xes, cs, combine, eps):
-        j, B = self._run(xes, cs, combine, _lib.NM_F_EXPORT, eps=eps)
-        locs = [j.out_loc[k][:B].clone().requires_grad_(True) for k in range(len(j.kmods))]
-        z = j.out_z[:B].clone().requires_grad_(True)
-        return j, B, locs, z
-
-    def _backward_with_head(self, head_loss, g):
-        xes, cs, combine, eps, locs, z = self._last
-        torch.autograd.backward(head_loss, g if torch.is_tensor(g) else torch.tensor(g))
-        j = self._job
-        ra = j.tables[0].rows_alloc
-        B = int(xes[0].shape[0])
-        for k, (m, _, _) in enumerate(j.kmods):
-            t = j.tables[m]
-            ex = torch.zeros(ra, t.x_pitch, device=self._device)
-            if locs[k].grad is not None:
-                ex[:B, :t.D] = locs[k].grad
-            j.dloc_extra[k] = ex
-        dz = torch.zeros(ra, self.spec.latent, device=self._device)
-        if z.grad is not None:
-            dz[:B] = z.grad
-        j.dz_extra = dz
-        j.kl_weight = self._kl_weight
-        j.ll_weight = getattr(self, "_ll_weight", 1.0)
-        j.touch()
-        self._run_keep_tables(_lib.NM_F_BACKWARD | _lib.NM_F_GRADS)
-        j.dz_extra = None
-        j.dloc_extra = [None] * len(j.kmods)
-        j.touch()
-        self._pending = j.grads
-        self._grads_ready = True
-        gv = self.layout.unflatten(self._pending)
-        for name, p in self._named_views():
-            if name in gv:
-                p.grad = gv[name]
-
-    def _run_keep_tables(self, flags):
-        j = self._job
-        j.step = 0
-        j.touch()
-        JobSet([j])._launch(0, 1, 1, flags)
+    """Models with a head on top of the trunk (regressor / classifier).  The head is its own HIP kernel that
+    runs between two trunk launches: the first exports x_hat / z / per-subject deviations, the head turns them
+    into its loss and into extra gradients on x_hat and z (nm_modality_t.dloc_extra / dloc_rowcoef,
+    nm_job_t.dz_extra), the second runs the trunk's forward + backward with those added."""
 
     def _named_views(self):
         return [(n, p) for n, p in self.named_parameters() if n in self.layout.offsets]
@@ -540,24 +471,27 @@ class cVAE_multimodal_regression(_HeadBase):
         return cVAE_multimodal._unimodal(self, m)
 
 
-class Classifier(nn.Module):
-    """cVAE.py:2004-2018."""
+class _E2ETotal(torch.autograd.Function):
+    """total_loss of the end-to-end model; backward runs the classifier head's backward (d CE / d z, hinge row
+    coefficients, its own gradients) and then the trunk launch that adds them to the weighted ELBO gradient."""
 
-    def __init__(self, latent_dim, classifier_layers, dropout_rate, num_classes=2):
-        super().__init__()
-        layers, sizes = [], [latent_dim] + list(classifier_layers)
-        for i in range(len(sizes) - 1):
-            layers += [nn.Linear(sizes[i], sizes[i + 1]), nn.BatchNorm1d(sizes[i + 1]), nn.ReLU(), nn.Dropout(dropout_rate)]
-        layers.append(nn.Linear(sizes[-1], num_classes))
-        self.classifier = nn.Sequential(*layers)
+    @staticmethod
+    def forward(ctx, anchor, model, value):
+        ctx.model = model
+        return value.clone()
 
-    def forward(self, z):
-        return self.classifier(z)
+    @staticmethod
+    def backward(ctx, g):
+        ctx.model._backward_native(float(g))
+        return None, None, None
 
 
 class cVAE_multimodal_endtoend(_HeadBase):
     """cVAE.py:2021-2207: shared encoders, PoE (no single-expert bypass), health + disease decoder banks,
-    classifier on z, loss = w_rec (NLL_h + NLL_d) + w_kl KL + CE + w_c contrastive hinge."""
+    classifier on z, loss = w_rec (NLL_h + NLL_d) + w_kl KL + CE + w_c contrastive hinge.  Trunk (nm_launch) and
+    classifier head (nm_head_classifier: Linear - BatchNorm1d - ReLU - Dropout blocks, cross entropy, hinge) both
+    run in HIP; the classifier's tensors, BatchNorm running statistics included, live in the flat parameter
+    buffer under the reference's names classifier.classifier.{i}.*."""
 
     def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
                  non_linear=False, classifier_layers=[128, 64], dropout_rate=0.5, num_classes=2):
@@ -565,11 +499,13 @@ class cVAE_multimodal_endtoend(_HeadBase):
         self.input_dim_list, self.latent_dim, self.c_dim = list(input_dim_list), latent_dim, c_dim
         self.hidden_dim = list(hidden_dim) + [latent_dim]
         self.modalities, self.learning_rate, self.non_linear, self.num_classes = modalities, learning_rate, non_linear, num_classes
-        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "endtoend"),
-                    learning_rate, kl_weight=0.1)
+        self.dropout_rate = float(dropout_rate)
+        self._nbt = [0] * len(classifier_layers)            # BatchNorm1d.num_batches_tracked
+        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "endtoend",
+                              tuple(classifier_layers), num_classes), learning_rate, kl_weight=0.1)
         self._ll_weight = 0.1
-        self.classifier = Classifier(latent_dim, classifier_layers, dropout_rate, num_classes)
-        self.optimizer = _AdamWithHead(self, learning_rate, self.classifier.parameters())
+        self._margin, self._wc = 1.0, 0.1
+        self.optimizer = _Adam(self, learning_rate)
 
     def _build_tree(self):
         v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
@@ -596,35 +532,60 @@ class cVAE_multimodal_endtoend(_HeadBase):
         self.encoder_list = nn.ModuleList([enc(m) for m in range(s.M)])
         self.decoder_list_health = nn.ModuleList([dec(m, "health") for m in range(s.M)])
         self.decoder_list_disease = nn.ModuleList([dec(m, "disease") for m in range(s.M)])
-
-    def to(self, device):
-        super().to(device)
-        self.classifier.to(self._device)
-        self.optimizer.head = torch.optim.Adam(self.classifier.parameters(), lr=self.learning_rate)
-        return self
+        self.classifier = nn.Module()                          # Classifier.classifier = nn.Sequential(...), cVAE.py:2015
+        seq = nn.Module()
+        n = len(s.classifier_layers)
+        for i in range(n):
+            p = f"classifier.classifier.{4 * i}"
+            seq.add_module(str(4 * i), _Holder(weight=v[f"{p}.weight"], bias=v[f"{p}.bias"]))
+            q = f"classifier.classifier.{4 * i + 1}"
+            seq.add_module(str(4 * i + 1), _Holder(weight=v[f"{q}.weight"], bias=v[f"{q}.bias"],
+                                                   running_mean=v[f"{q}.running_mean"], running_var=v[f"{q}.running_var"]))
+        p = f"classifier.classifier.{4 * n}"
+        seq.add_module(str(4 * n), _Holder(weight=v[f"{p}.weight"], bias=v[f"{p}.bias"]))
+        self.classifier.classifier = seq
 
     def state_dict(self, *a, **k):
-        sd = _Base.state_dict(self)
-        sd.update({f"classifier.{n}": v.detach().cpu().clone() for n, v in self.classifier.state_dict().items()})
-        return sd
+        out = {}
+        for name, t in _Base.state_dict(self).items():
+            out[name] = t
+            if name.endswith(".running_var"):                  # reference key order: ..., running_var, num_batches_tracked
+                i = (int(name.split(".")[2]) - 1) // 4
+                out[name[: -len("running_var")] + "num_batches_tracked"] = torch.tensor(self._nbt[i], dtype=torch.int64)
+        return out
 
     def load_state_dict(self, state, strict: bool = True):
-        _Base.load_state_dict(self, {k: v for k, v in state.items() if not k.startswith("classifier.")})
-        self.classifier.load_state_dict({k[len("classifier."):]: v for k, v in state.items() if k.startswith("classifier.")})
-        return self
+        for k, v in state.items():
+            if k.endswith("num_batches_tracked"):
+                self._nbt[(int(k.split(".")[2]) - 1) // 4] = int(v)
+        return _Base.load_state_dict(self, {k: v for k, v in state.items() if not k.endswith("num_batches_tracked")})
 
     def _scale_bank(self, m, bank):
         return self._views()[f"{self.spec.dec_prefix(m, bank)}logvar_out"].exp().pow(0.5)
 
+    def _head_setup(self, j, use_mu: bool, labels=None):
+        j.cls_train, j.cls_use_mu = bool(self.training), use_mu
+        j.cls_dropout = self.dropout_rate
+        j.cls_margin, j.cls_w_ce, j.cls_w_contrast = self._margin, 1.0, self._wc
+        if labels is None:
+            j.labels = None
+        else:
+            j.set_labels(labels)
+        j.touch()
+
     def forward(self, xes, cs):
         eps = self._draw(int(xes[0].shape[0]))
-        j, B, locs, z = self._trunk_forward(xes, cs, "poe", eps)
+        j, B = self._run(xes, cs, "poe", _lib.NM_F_EXPORT, eps=eps)
+        self._head_setup(j, use_mu=False)
+        JobSet([j]).head_classifier(backward=False, bn_stats=self.training)                  # cVAE.py:2117
+        if self.training:
+            self._nbt = [n + 1 for n in self._nbt]
         M = self.modalities
-        logits = self.classifier(z)
-        self._last = (list(xes), list(cs), "poe", eps, locs, z)
-        return {"x_recons_health": [NormalLike(locs[m], self._scale_bank(m, "health")) for m in range(M)],
-                "x_recons_disease": [NormalLike(locs[M + m], self._scale_bank(m, "disease")) for m in range(M)],
-                "mu": j.out_mu[:B].clone(), "logvar": j.out_logvar[:B].clone(), "logits": logits}
+        self._last = (list(xes), list(cs), "poe", eps)
+        return {"x_recons_health": [NormalLike(j.out_loc[m][:B].clone(), self._scale_bank(m, "health")) for m in range(M)],
+                "x_recons_disease": [NormalLike(j.out_loc[M + m][:B].clone(), self._scale_bank(m, "disease")) for m in range(M)],
+                "mu": j.out_mu[:B].clone(), "logvar": j.out_logvar[:B].clone(),
+                "logits": j.out_logits[:B, : self.num_classes].clone()}
 
     def calc_kl(self, mu, logvar):
         return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1).mean()
@@ -633,26 +594,52 @@ class cVAE_multimodal_endtoend(_HeadBase):
         return ((x - x_recon.mean) ** 2).mean(dim=1)                          # cVAE.py:2134-2138
 
     def loss_function(self, xes, fwd_rtn, labels, margin=1.0, weightcontrastive=0.1, weight_kl=0.1, weight_rec=0.1):
-        if abs(weight_kl - self._kl_weight) > 0 or abs(weight_rec - 0.1) > 0:
-            self._kl_weight = float(weight_kl)
-        M = self.modalities
-        xs = [x.to(self._device, torch.float32) for x in xes]
-        labels = labels.to(self._device)
-        row = self._job.loss_log[0]
+        j, M = self._job, self.modalities
+        self._margin, self._wc = float(margin), float(weightcontrastive)
+        self._kl_weight, self._ll_weight = float(weight_kl), float(weight_rec)
+        # cross entropy and hinge come from the head kernel (same dropout mask: the generator is keyed by the step)
+        self._head_setup(j, use_mu=False, labels=labels)
+        JobSet([j]).head_classifier(backward=False)
+        row = j.loss_log[0]
         ll_m = row[3:3 + 2 * M]
         recon_h, recon_d = -ll_m[:M].sum(), -ll_m[M:].sum()
-        dev_h = torch.stack([self.compute_deviation(xs[m], fwd_rtn["x_recons_health"][m]) for m in range(M)]).mean(dim=0)
-        dev_d = torch.stack([self.compute_deviation(xs[m], fwd_rtn["x_recons_disease"][m]) for m in range(M)]).mean(dim=0)
-        contrastive = torch.mean((1 - labels) * torch.relu(margin + dev_h - dev_d) + labels * torch.relu(margin + dev_d - dev_h))
         kl = self.calc_kl(fwd_rtn["mu"], fwd_rtn["logvar"])
-        ce = torch.nn.functional.cross_entropy(fwd_rtn["logits"], labels)
-        self._ll_weight = float(weight_rec)
-        trunk = weight_rec * (recon_h + recon_d) + weight_kl * kl
-        total = _HeadTrunkLoss.apply(self._anchor, self, trunk.detach(), [ce + weightcontrastive * contrastive])
+        ce, contrastive = row[_lib.NM_LOSS_CE].clone(), row[_lib.NM_LOSS_CONTRAST].clone()
+        value = weight_rec * (recon_h + recon_d) + weight_kl * kl + ce + weightcontrastive * contrastive
+        total = _E2ETotal.apply(self._anchor, self, value.detach())
         return {"total_loss": total, "recon_loss_health": recon_h.clone(), "recon_loss_disease": recon_d.clone(),
                 "kl_loss": kl, "classification_loss": ce, "contrastive_loss": contrastive}
+
+    def _backward_native(self, g: float):
+        j = self._job
+        j.prepare_classifier()
+        j.dz_extra.zero_()
+        for t in j.dloc_rowcoef:
+            t.zero_()
+        j.cls_w_ce, j.cls_w_contrast = g, self._wc * g
+        j.kl_weight, j.ll_weight = self._kl_weight * g, self._ll_weight * g
+        j.step = 0
+        j.touch()
+        js = JobSet([j])
+        js.head_classifier(backward=True, grads=True)            # d CE / d z, hinge row coefficients, classifier grads
+        js._launch(0, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS)  # trunk: weighted ELBO + those extras
+        j.dz_extra = None
+        j.dloc_rowcoef = [None] * len(j.kmods)
+        j.cls_w_ce, j.cls_w_contrast = 1.0, self._wc
+        j.kl_weight, j.ll_weight = self._kl_weight, self._ll_weight
+        j.touch()
+        self._pending = j.grads
+        self._grads_ready = True
+        gv = self.layout.unflatten(self._pending)
+        for name, p in self._named_views():
+            if name in gv:
+                p.grad = gv[name]
 
     def predict(self, xes, cs):
         with torch.no_grad():
             j, B = self._run(xes, cs, "poe", _lib.NM_F_EXPORT)
-            return self.classifier(j.out_mu[:B].clone())
+            self._head_setup(j, use_mu=True)                     # classifier(mu_combined), cVAE.py:2202-2207
+            JobSet([j]).head_classifier(backward=False, bn_stats=self.training)
+            if self.training:
+                self._nbt = [n + 1 for n in self._nbt]
+            return j.out_logits[:B, : self.num_classes].clone()

@@ -1068,13 +1068,16 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             nvalid += rv ? 1 : 0;
             bf16x4 pk;
             f32x4 ex = {0.f, 0.f, 0.f, 0.f};
-            if (md.dloc_extra)               // extra loss gradient on x_hat (regression head / contrastive hinge)
+            if (md.dloc_extra)               // extra loss gradient on x_hat (regression head)
               ex = *(const GAS f32x4*)(asg(md.dloc_extra) + (int64_t)(c.row0 + r) * xp + min(dg0, xp - 4));
+            float rc = 0.f;
+            if (md.dloc_rowcoef) rc = asg(md.dloc_rowcoef)[c.row0 + r];      // contrastive hinge: rc * (x_hat - x)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float diff = rv ? acc[t][rt][i] - xcur[rt][i] : 0.f;
               colq[i] = fmaf(diff, diff, colq[i]);
-              pk[i] = (__bf16)(diff * coef[i] + ((rv && dg0 + i < D) ? ex[i] : 0.f));
+              const bool dv = dg0 + i < D;
+              pk[i] = (__bf16)(diff * (coef[i] + (dv ? rc : 0.f)) + ((rv && dv) ? ex[i] : 0.f));
             }
             if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
           }
@@ -1606,6 +1609,369 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   }
 }
 
+// ---- classifier head of the end-to-end model (cVAE.py:2004-2018 Classifier, 2117 logits, 2140-2200 loss) ---
+// One workgroup per (job, 256-row tile).  Blocks of Linear - BatchNorm1d - ReLU - Dropout, then Linear to the
+// class logits; cross entropy (mean over rows) and the contrastive hinge on the per-subject deviations the
+// trunk exported.  Backward returns d CE / d z (dz_out) and, per decoder, the row coefficient of the hinge
+// gradient (rowcoef_out), and applies / stores the classifier's own gradients.
+struct ClsWs {
+  gbf16 hin[NM_MAX_CLS + 1];
+  gf32 xhat[NM_MAX_CLS];
+  gf32 rstd[NM_MAX_CLS];
+};
+__host__ __device__ inline int64_t cls_ws_bytes() {
+  return (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)NM_MAX_CLS * ROWS * PW * 4 + (int64_t)NM_MAX_CLS * PW * 4;
+}
+// column sums over the rows of per-lane values v[t][i] (feature (wn+4t)*16+4g+i) into dst[feature]
+__device__ __forceinline__ void col_reduce(const Ctx& c, const float (&v)[2][4], float* dst, int N) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = v[t][i];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      const int f = (c.wn + 4 * t) * 16 + 4 * c.g + i;
+      if (c.c16 == 0 && f < N) atomicAdd(&dst[f], s);
+    }
+}
+__device__ __forceinline__ float uniform_ctr(uint64_t seed, uint32_t step, uint32_t layer, uint32_t row, uint32_t f) {
+  uint64_t h = splitmix64(seed ^ 0xC1A551F1E5ull ^ ((uint64_t)step << 32) ^ ((uint64_t)layer << 28) ^ ((uint64_t)row << 8) ^ f);
+  return (uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const nm_job_t* J = jobs + blockIdx.x;
+  Ctx c;
+  c.job = J;
+  carve_lds(c, smem);
+  relaunder(c);
+  c.flags = flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS);
+  c.t_last = 0;
+  c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
+  for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  __syncthreads();
+  c.row0 = (tile0 + (int)blockIdx.y) * ROWS;
+  c.nrows = min(ROWS, J->n_rows - c.row0);
+  if (c.nrows <= 0) return;
+  c.inv_b = 1.0f / (float)c.nrows;
+  const double tt = (double)(J->adam_off + (int64_t)step + 1);
+  c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
+  c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+  const bool train = J->cls_train != 0;
+  const bool bwd = (flags & NM_F_BACKWARD) != 0 && train && J->labels != nullptr;
+  const int Lc = J->cls_layers, C = J->cls_classes, Z = J->Z;
+  const float Bf = (float)c.nrows;
+  gcf32 prm = asg(J->params);
+  float* col1 = c.colacc;
+  float* col2 = c.stage;
+  ClsWs W;
+  {
+    GAS char* p = c.ws;
+    for (int i = 0; i <= NM_MAX_CLS; ++i) { W.hin[i] = (gbf16)p; p += (int64_t)ROWS * PW * 2; }
+    for (int i = 0; i < NM_MAX_CLS; ++i) { W.xhat[i] = (gf32)p; p += (int64_t)ROWS * PW * 4; }
+    for (int i = 0; i < NM_MAX_CLS; ++i) { W.rstd[i] = (gf32)p; p += (int64_t)PW * 4; }
+  }
+  const float keep_scale = (train && J->cls_dropout > 0.f) ? 1.0f / (1.0f - J->cls_dropout) : 1.0f;
+
+  // ---- P <- z (or the joint mean for predict) ----
+  {
+    const int Kz = rup(Z, 32);
+    const float rk = 1.0f / (float)Kz;
+    gcf32 zsrc = asg((const float*)(J->cls_use_mu ? J->out_mu : J->out_z));
+    for (int e = c.tid; e < ROWS * Kz; e += WG) {
+      const int r = idiv(e, Kz, rk), k = e - r * Kz;
+      const float v = zsrc[(int64_t)(c.row0 + min(r, c.nrows - 1)) * Z + min(k, Z - 1)];
+      c.P[r * LDP + k] = (__bf16)((k < Z && r < c.nrows) ? v : 0.f);
+    }
+  }
+  lds_barrier();
+
+  f32x4 acc[2][RT];
+  // ---- hidden blocks ----
+  for (int li = 0; li < Lc; ++li) {
+    relaunder(c);
+    const int K = li == 0 ? Z : J->cls_width[li - 1], N = J->cls_width[li], K32 = rup(K, 32);
+    gcf32 Wl = prm + J->cls_w[li];
+    if (bwd) store_act(c, W.hin[li], c.P, K32);
+    bias_acc(c, acc, prm + J->cls_b[li], N, 0);
+    for (int ks = 0; ks < K32 / 32; ++ks) {
+      bf16x8 wf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wf[t] = w_frag(Wl, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+      }
+    }
+    if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
+    __syncthreads();                               // P fully read; column accumulators cleared
+    float mean[2][4], rstd[2][4], gam[2][4], bet[2][4];
+    if (train) {                                   // batch statistics over the valid rows (biased variance)
+      float v[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s = 0.f;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) s += (c.wm * WROWS + rt * 16 + c.c16 < c.nrows) ? acc[t][rt][i] : 0.f;
+          v[t][i] = s;
+        }
+      col_reduce(c, v, col1, N);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = min((c.wn + 4 * t) * 16 + 4 * c.g + i, PW - 1);
+          mean[t][i] = col1[f] / Bf;
+          float s = 0.f;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const float d = acc[t][rt][i] - mean[t][i];
+            s += (c.wm * WROWS + rt * 16 + c.c16 < c.nrows) ? d * d : 0.f;
+          }
+          v[t][i] = s;
+        }
+      col_reduce(c, v, col2, N);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = (c.wn + 4 * t) * 16 + 4 * c.g + i, fc = min(f, N - 1);
+        float var;
+        if (train) { var = col2[min(f, PW - 1)] / Bf; }
+        else { mean[t][i] = prm[J->cls_bn_mean[li] + fc]; var = prm[J->cls_bn_var[li] + fc]; }
+        rstd[t][i] = 1.0f / sqrtf(var + 1e-5f);
+        gam[t][i] = prm[J->cls_bn_w[li] + fc];
+        bet[t][i] = prm[J->cls_bn_b[li] + fc];
+      }
+    if (c.tid < N && train) {                      // per-feature rstd for the backward pass; running statistics
+      const float m = col1[c.tid] / Bf, var = col2[c.tid] / Bf;
+      if (bwd) W.rstd[li][c.tid] = 1.0f / sqrtf(var + 1e-5f);
+      if ((flags & NM_F_BNSTATS) && blockIdx.y == 0) {
+        gf32 rm = asg(J->params) + J->cls_bn_mean[li] + c.tid, rv = asg(J->params) + J->cls_bn_var[li] + c.tid;
+        const float unb = c.nrows > 1 ? var * Bf / (Bf - 1.0f) : var;      // running_var takes the unbiased estimate
+        *rm = 0.9f * *rm + 0.1f * m;
+        *rv = 0.9f * *rv + 0.1f * unb;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+      if (f0 >= rup(N, 32)) continue;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = c.wm * WROWS + rt * 16 + c.c16;
+        f32x4 xh;
+        bf16x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xh[i] = (acc[t][rt][i] - mean[t][i]) * rstd[t][i];
+          float h = fmaxf(gam[t][i] * xh[i] + bet[t][i], 0.f);
+          if (train && J->cls_dropout > 0.f)
+            h = uniform_ctr(J->seed, (uint32_t)step, (uint32_t)li, (uint32_t)(c.row0 + r), (uint32_t)(f0 + i)) >= J->cls_dropout
+                    ? h * keep_scale : 0.f;
+          pk[i] = (__bf16)((f0 + i < N && r < c.nrows) ? h : 0.f);
+        }
+        if (bwd) *(GAS f32x4*)(W.xhat[li] + r * PW + f0) = xh;
+        *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
+      }
+    }
+    lds_barrier();
+  }
+
+  // ---- output layer, cross entropy ----
+  relaunder(c);
+  const int Kl = Lc ? J->cls_width[Lc - 1] : Z, Kl32 = rup(Kl, 32);
+  gcf32 Wo = prm + J->cls_w[Lc];
+  if (bwd) store_act(c, W.hin[Lc], c.P, Kl32);
+  bias_acc(c, acc, prm + J->cls_b[Lc], C, 0);
+  for (int ks = 0; ks < Kl32 / 32; ++ks) {
+    bf16x8 wf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wf[t] = w_frag(Wo, C, Kl, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+    }
+  }
+  lds_barrier();
+  for (int e = c.tid; e < ROWS * 32; e += WG) c.P[(e >> 5) * LDP + (e & 31)] = (__bf16)0.0f;   // d logits land here
+  lds_barrier();
+  float ce = 0.f;
+  if (c.wn == 0 && c.g == 0) {                     // these lanes hold logits 0..3 of their rows
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int r = c.wm * WROWS + rt * 16 + c.c16;
+      if (r < c.nrows) {
+        float l[NM_MAX_CLASSES], mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < NM_MAX_CLASSES; ++k) { l[k] = acc[0][rt][k]; if (k < C) mx = fmaxf(mx, l[k]); }
+        if (J->out_logits)
+#pragma unroll
+          for (int k = 0; k < NM_MAX_CLASSES; ++k)
+            asg(J->out_logits)[(int64_t)(c.row0 + r) * NM_MAX_CLASSES + k] = k < C ? l[k] : 0.f;
+        if (J->labels) {
+          const int y = asg(J->labels)[c.row0 + r];
+          float se = 0.f;
+#pragma unroll
+          for (int k = 0; k < NM_MAX_CLASSES; ++k) se += k < C ? expf(l[k] - mx) : 0.f;
+          const float lse = mx + logf(se);
+#pragma unroll
+          for (int k = 0; k < NM_MAX_CLASSES; ++k) {
+            if (k == y) ce += lse - l[k];
+            if (bwd && k < C) c.P[r * LDP + k] = (__bf16)((expf(l[k] - lse) - (k == y ? 1.f : 0.f)) * J->cls_w_ce * c.inv_b);
+          }
+        }
+      }
+    }
+  }
+  const float ce_sum = block_sum(c, ce);
+  // ---- contrastive hinge on the per-subject deviations (cVAE.py:2166-2182) ----
+  const int Me = experts(J);
+  float hinge = 0.f;
+  if (J->labels && c.tid < c.nrows && J->M >= 2 * Me) {
+    const int gr = c.row0 + c.tid;
+    float dh = 0.f, dd = 0.f;
+    bool have = true;
+    for (int m = 0; m < Me; ++m) {
+      have = have && J->mod[m].out_rowdev && J->mod[Me + m].out_rowdev;
+      if (have) { dh += asg(J->mod[m].out_rowdev)[gr]; dd += asg(J->mod[Me + m].out_rowdev)[gr]; }
+    }
+    if (have) {
+      dh /= (float)Me; dd /= (float)Me;
+      const int y = asg(J->labels)[gr];
+      const float tval = y ? J->cls_margin + dd - dh : J->cls_margin + dh - dd;
+      hinge = fmaxf(tval, 0.f);
+      if (bwd) {
+        const float gt = tval > 0.f ? J->cls_w_contrast * c.inv_b : 0.f;      // d total / d tval
+        const float g_h = y ? -gt : gt;                                       // d / d dev_health; disease = -g_h
+        for (int m = 0; m < Me; ++m) {
+          if (J->rowcoef_out[m]) asg(J->rowcoef_out[m])[gr] = g_h * 2.0f / ((float)Me * (float)J->mod[m].D);
+          if (J->rowcoef_out[Me + m]) asg(J->rowcoef_out[Me + m])[gr] = -g_h * 2.0f / ((float)Me * (float)J->mod[Me + m].D);
+        }
+      }
+    }
+  }
+  const float hinge_sum = block_sum(c, hinge);
+  if (c.tid == 0 && J->loss_log && J->labels && blockIdx.y == 0) {
+    gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
+    row[NM_LOSS_CE] = ce_sum * c.inv_b;
+    row[NM_LOSS_CONTRAST] = hinge_sum * c.inv_b;
+  }
+  if (!bwd) return;
+
+  // ---- backward: output layer ----
+  relaunder(c);
+  load_act(c, c.Q, W.hin[Lc], Kl32);
+  lds_barrier();
+  zero_acc(acc);
+  dgrad_acc(c, acc, c.P, Wo, C, Kl, 1, 0);
+  float gb = 0.f;
+  if (c.tid < C) for (int r = 0; r < ROWS; ++r) gb += (float)c.P[r * LDP + c.tid];
+  lds_barrier();                                   // Wo fully read before its update
+  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, C, Kl, 0, rup(Kl, 16), J->cls_w[Lc], -1);
+  if (c.tid < C) apply_grad(c, J->cls_b[Lc] + c.tid, gb);
+  // ---- backward: hidden blocks ----
+  for (int li = Lc - 1; li >= 0; --li) {
+    relaunder(c);
+    const int K = li == 0 ? Z : J->cls_width[li - 1], N = J->cls_width[li], K32 = rup(K, 32);
+    gcf32 Wl = prm + J->cls_w[li];
+    // acc = d h (pre-mask), Q = h of this block.  d y = d h * relu'/dropout mask; BatchNorm backward needs the
+    // column sums S1 = sum d y, S2 = sum d y * x_hat
+    if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
+    __syncthreads();
+    float v1[2][4], v2[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v1[t][i] = 0.f; v2[t][i] = 0.f; }
+      if (f0 >= rup(N, 32)) continue;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = c.wm * WROWS + rt * 16 + c.c16;
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(c.Q + r * LDP + f0);
+        const f32x4 xh = *(const GAS f32x4*)(W.xhat[li] + r * PW + f0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dy = ((float)h[i] > 0.f && r < c.nrows && f0 + i < N) ? acc[t][rt][i] * keep_scale : 0.f;
+          acc[t][rt][i] = dy;
+          v1[t][i] += dy;
+          v2[t][i] = fmaf(dy, xh[i], v2[t][i]);
+        }
+      }
+    }
+    col_reduce(c, v1, col1, N);
+    col_reduce(c, v2, col2, N);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+      if (f0 >= rup(N, 32)) continue;
+      float s1[4], s2[4], gr_[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int fc = min(f0 + i, N - 1);
+        s1[i] = col1[min(f0 + i, PW - 1)] * c.inv_b;
+        s2[i] = col2[min(f0 + i, PW - 1)] * c.inv_b;
+        gr_[i] = prm[J->cls_bn_w[li] + fc] * W.rstd[li][fc];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = c.wm * WROWS + rt * 16 + c.c16;
+        const f32x4 xh = *(const GAS f32x4*)(W.xhat[li] + r * PW + f0);
+        bf16x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float da = gr_[i] * (acc[t][rt][i] - s1[i] - xh[i] * s2[i]);
+          pk[i] = (__bf16)((r < c.nrows && f0 + i < N) ? da : 0.f);
+        }
+        *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
+      }
+    }
+    __syncthreads();                               // gamma has been read by everyone: its update may go ahead
+    if (c.tid < N) {                               // d gamma = S2, d beta = S1
+      apply_grad(c, J->cls_bn_w[li] + c.tid, col2[c.tid]);
+      apply_grad(c, J->cls_bn_b[li] + c.tid, col1[c.tid]);
+    }
+    load_act(c, c.Q, W.hin[li], K32);
+    lds_barrier();
+    float gbi = 0.f;
+    if (c.tid < N) for (int r = 0; r < ROWS; ++r) gbi += (float)c.P[r * LDP + c.tid];
+    zero_acc(acc);
+    dgrad_acc(c, acc, c.P, Wl, N, K, rup(N, 32) / 32, 0);
+    lds_barrier();
+    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N, K, 0, rup(K, 16), J->cls_w[li], -1);
+    if (c.tid < N) apply_grad(c, J->cls_b[li] + c.tid, gbi);
+  }
+  // ---- d CE / d z ----
+  if (J->dz_out) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = c.wm * WROWS + rt * 16 + c.c16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (r < c.nrows && k0 + i < Z) asg(J->dz_out)[(int64_t)(c.row0 + r) * Z + k0 + i] = acc[t][rt][i];
+      }
+    }
+  }
+}
+
 // ---- stand-alone kernels ----------------------------------------------------------------------
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
@@ -1729,7 +2095,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 3; }
+int nm_version(void) { return 4; }
 
 /* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {
@@ -1775,6 +2141,7 @@ const char* nm_status_string(int status) {
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
     case -10: return "parameter tensor offsets must be multiples of 4 floats";
+    case -13: return "classifier head: 0..NM_MAX_CLS blocks of width 1..128, 2..NM_MAX_CLASSES classes, offsets multiples of 4, out_mu/out_z export";
     case -12: return "metrics: n_sets >= 1 and 1 <= max_set <= NM_METRICS_MAX_N";
     case -11: return "regression head: needs reg_w / reg_b offsets (multiples of 4) and every expert's out_loc export";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
@@ -1799,6 +2166,15 @@ int nm_validate_job(const nm_job_t* j) {
       if ((md.enc_w[i] | md.enc_b[i] | md.dec_w[i] | md.dec_b[i]) & 3) return -10;
     if ((md.mu_w | md.mu_b | md.lv_w | md.lv_b | md.logvar_out | md.out_w | md.out_b) & 3) return -10;
   }
+  if (j->cls_classes > 0) {
+    if (j->cls_layers < 0 || j->cls_layers > NM_MAX_CLS || j->cls_classes < 2 || j->cls_classes > NM_MAX_CLASSES) return -13;
+    for (int i = 0; i < j->cls_layers; ++i) {
+      if (j->cls_width[i] < 1 || j->cls_width[i] > PW) return -13;
+      if ((j->cls_w[i] | j->cls_b[i] | j->cls_bn_w[i] | j->cls_bn_b[i] | j->cls_bn_mean[i] | j->cls_bn_var[i]) & 3) return -13;
+    }
+    if ((j->cls_w[j->cls_layers] | j->cls_b[j->cls_layers]) & 3) return -13;
+    if (!(j->cls_use_mu ? j->out_mu : j->out_z)) return -13;
+  }
   if (j->reg_head) {
     for (int i = 0; i < 3; ++i)
       if (j->reg_w[i] < 0 || j->reg_b[i] < 0 || ((j->reg_w[i] | j->reg_b[i]) & 3)) return -11;
@@ -1810,7 +2186,9 @@ int nm_validate_job(const nm_job_t* j) {
 
 int64_t nm_workspace_bytes(const nm_job_t* j) {
   if (!j) return -1;
-  return ws_layout(j->M, j->L, j->Z).total;
+  int64_t b = ws_layout(j->M, j->L, j->Z).total;
+  if (j->cls_layers > 0 || j->cls_classes > 0) b = b > cls_ws_bytes() ? b : (cls_ws_bytes() + 255) / 256 * 256;
+  return b;
 }
 
 static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
@@ -1849,6 +2227,16 @@ int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0
   hipError_t e = hipFuncSetAttribute((const void*)nm_reghead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nm_reghead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,
+                     tile0, flags);
+  return (int)hipGetLastError();
+}
+
+int nm_head_classifier(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags, void* stream) {
+  if (!jobs_dev) return -1;
+  if (n_jobs < 1 || n_tiles < 1 || step < 0 || tile0 < 0) return -8;
+  hipError_t e = hipFuncSetAttribute((const void*)nm_clshead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(nm_clshead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,
                      tile0, flags);
   return (int)hipGetLastError();
 }

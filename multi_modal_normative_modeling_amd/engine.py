@@ -102,6 +102,12 @@ class Job:
         self.dz_extra: Optional[torch.Tensor] = None  # d L_extra / d z          [rows_alloc, Z]
         self.dloc_extra: List[Optional[torch.Tensor]] = [None] * len(self.kmods)   # d L_extra / d x_hat [rows_alloc, x_pitch]
         self.ll_weight = float(ll_weight)
+        # classifier head (kind == "endtoend" with classifier_layers)
+        self.dloc_rowcoef: List[Optional[torch.Tensor]] = [None] * len(self.kmods)      # hinge row coefficients [rows_alloc]
+        self.labels: Optional[torch.Tensor] = None    # int32 [rows_alloc]
+        self.out_logits: Optional[torch.Tensor] = None
+        self.cls_train, self.cls_use_mu = True, False
+        self.cls_dropout, self.cls_margin, self.cls_w_ce, self.cls_w_contrast = 0.0, 1.0, 1.0, 0.1
         self.reg_lambda = 1.0                         # regression head (kind == "regression")
         self.fi_target: Optional[torch.Tensor] = None # [rows_alloc]
         self.out_fi_pred: Optional[torch.Tensor] = None
@@ -131,6 +137,7 @@ class Job:
         lib = _lib.load()
         probe = _lib.NmJob()
         probe.M, probe.L, probe.Z = len(self.kmods), len(self.spec.hidden), self.spec.latent
+        probe.cls_layers, probe.cls_classes = len(self.spec.classifier_layers), (self.spec.num_classes if self.spec.classifier_layers else 0)
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
@@ -145,6 +152,29 @@ class Job:
         self.fi_target = torch.zeros(ra, device=self.device)
         self.fi_target[: f.numel()] = f.to(self.device)
         self._version += 1
+
+    def set_labels(self, labels):
+        """Class label per table row (classifier head); padded with zeros to rows_alloc."""
+        ra = self.tables[0].rows_alloc
+        l = torch.as_tensor(labels).reshape(-1).to(torch.int32)
+        if l.numel() != self.tables[0].N:
+            raise ValueError(f"labels has {l.numel()} values for {self.tables[0].N} table rows")
+        self.labels = torch.zeros(ra, dtype=torch.int32, device=self.device)
+        self.labels[: l.numel()] = l.to(self.device)
+        self._version += 1
+
+    def prepare_classifier(self):
+        """Buffers the end-to-end train loop needs: exports (latent, per-subject deviations, logits) and the
+        slots the head's backward fills (d CE / d z, hinge row coefficients)."""
+        if self.out_z is None or any(o is None for o in self.out_rowdev) or self.out_logits is None:
+            self.enable_exports(loc=False, sqerr=False, rowdev=True, latent=True)
+        ra = self.tables[0].rows_alloc
+        if self.dz_extra is None:
+            self.dz_extra = torch.zeros(ra, self.spec.latent, device=self.device)
+            self._version += 1
+        if any(d is None for d in self.dloc_rowcoef):
+            self.dloc_rowcoef = [torch.zeros(ra, device=self.device) for _ in self.kmods]
+            self._version += 1
 
     def prepare_regression(self):
         """Buffers the regression train loop needs: exported reconstructions and the d MSE / d x_hat slots."""
@@ -185,6 +215,8 @@ class Job:
             self.out_z = torch.zeros(ra, Z, device=self.device)
         if self.spec.kind == "regression":
             self.out_fi_pred = torch.zeros(ra, device=self.device)
+        if self.spec.kind == "endtoend" and self.spec.classifier_layers:
+            self.out_logits = torch.zeros(ra, _lib.NM_MAX_CLASSES, device=self.device)
         for j, (m, _, _) in enumerate(self.kmods):
             t = self.tables[m]
             self.out_loc[j] = torch.zeros(ra, t.D, device=self.device) if loc else None
@@ -222,6 +254,14 @@ class Job:
         j.reg_lambda = self.reg_lambda
         j.fi_target = self.fi_target.data_ptr() if self.fi_target is not None else None
         j.out_fi_pred = self.out_fi_pred.data_ptr() if self.out_fi_pred is not None else None
+        if j.cls_classes and (self.out_z is None or self.out_mu is None):
+            j.cls_layers, j.cls_classes = 0, 0        # the head reads the exported latent
+        j.cls_train, j.cls_use_mu = int(self.cls_train), int(self.cls_use_mu)
+        j.cls_dropout, j.cls_margin = self.cls_dropout, self.cls_margin
+        j.cls_w_ce, j.cls_w_contrast = self.cls_w_ce, self.cls_w_contrast
+        j.labels = self.labels.data_ptr() if self.labels is not None else None
+        j.out_logits = self.out_logits.data_ptr() if self.out_logits is not None else None
+        j.dz_out = self.dz_extra.data_ptr() if self.dz_extra is not None else None
         for k, (m, _, _) in enumerate(self.kmods):
             t = self.tables[m]
             md = j.mod[k]
@@ -232,6 +272,8 @@ class Job:
             md.out_sqerr = self.out_sqerr[k].data_ptr() if self.out_sqerr[k] is not None else None
             md.out_rowdev = self.out_rowdev[k].data_ptr() if self.out_rowdev[k] is not None else None
             md.dloc_extra = self.dloc_extra[k].data_ptr() if self.dloc_extra[k] is not None else None
+            md.dloc_rowcoef = self.dloc_rowcoef[k].data_ptr() if self.dloc_rowcoef[k] is not None else None
+            j.rowcoef_out[k] = md.dloc_rowcoef
         _lib.check(_lib.load().nm_validate_job(C.byref(j)), "nm_validate_job")
         return j
 
@@ -318,6 +360,42 @@ class JobSet:
                 (_lib.NM_F_ADAM if adam and backward else 0)
         _lib.check(self.lib.nm_head_regression(ptr, len(self.jobs), int(step), int(tile0), int(n_tiles), int(flags),
                                                _stream_ptr(self.device)), "nm_head_regression")
+
+    def head_classifier(self, backward: bool, grads: bool = True, adam: bool = False, bn_stats: bool = False,
+                        step: int = 0, tile0: int = 0, n_tiles: int = 1):
+        """nm_head_classifier on the latent / deviations a preceding NM_F_EXPORT launch exported: fills out_logits
+        and loss_log[..][NM_LOSS_CE / NM_LOSS_CONTRAST]; with backward also dz_extra, the hinge row coefficients
+        and the classifier's gradients / Adam update (cVAE.py:2004-2018, 2140-2200)."""
+        ptr = self._upload(max(n_tiles, 1))
+        flags = (_lib.NM_F_BACKWARD if backward else 0) | (_lib.NM_F_GRADS if grads and backward else 0) | \
+                (_lib.NM_F_ADAM if adam and backward else 0) | (_lib.NM_F_BNSTATS if bn_stats else 0)
+        _lib.check(self.lib.nm_head_classifier(ptr, len(self.jobs), int(step), int(tile0), int(n_tiles), int(flags),
+                                               _stream_ptr(self.device)), "nm_head_classifier")
+
+    def train_endtoend(self, n_steps: int):
+        """n_steps train steps of cVAE_multimodal_endtoend jobs on the device, no host sync (the loop of
+        multimodal_kfold_cvae_nmpmcont.py:257-303): per step (i) forward with latent and per-subject deviations
+        exported, (ii) the classifier head: forward (train-mode BatchNorm / Dropout), cross entropy, contrastive
+        hinge, backward, its Adam update, d CE / d z and the hinge row coefficients, (iii) the trunk's fused
+        forward + weighted ELBO + backward + Adam with those extra gradients."""
+        step0 = self.jobs[0].step
+        for j in self.jobs:
+            if j.spec.kind != "endtoend" or not j.spec.classifier_layers or j.labels is None:
+                raise ValueError("train_endtoend needs end-to-end jobs with a classifier and labels set")
+            if j.step != step0:
+                raise ValueError("jobs of one set must be at the same step")
+            j.cls_train, j.cls_use_mu = True, False
+            j.prepare_classifier()
+        nb = self.jobs[0].batches_per_epoch
+        if any(j.batches_per_epoch != nb for j in self.jobs):
+            raise ValueError("jobs of one set must have the same number of batches")
+        for s in range(step0, step0 + n_steps):
+            self._launch(s, 1, 1, _lib.NM_F_EXPORT)
+            self.head_classifier(backward=True, grads=False, adam=True, bn_stats=True, step=s, tile0=s % nb)
+            self._launch(s, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)
+        for j in self.jobs:
+            j.step += n_steps
+            j.t += n_steps
 
     def train_regression(self, n_steps: int):
         """n_steps train steps of cVAE_multimodal_regression jobs, everything on the device, no host sync

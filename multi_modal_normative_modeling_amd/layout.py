@@ -32,6 +32,9 @@ class ModelSpec:
     # "single" = class cVAE, "multimodal" = cVAE_multimodal, "regression" = cVAE_multimodal_regression (trunk),
     # "endtoend" = cVAE_multimodal_endtoend (trunk: shared encoders + health / disease decoder banks)
     kind: str = "multimodal"
+    # end-to-end model only: hidden widths of the Classifier (cVAE.py:2004-2018); () = trunk without a classifier
+    classifier_layers: Sequence[int] = ()
+    num_classes: int = 2
 
     @property
     def M(self) -> int:
@@ -49,6 +52,10 @@ class ModelSpec:
             raise ValueError(f"latent_dim must be 1..{_lib.NM_MAX_LATENT}, got {self.latent}")
         if self.latent + self.c_dim > _lib.NM_MAX_WIDTH:
             raise ValueError(f"latent_dim + c_dim must be <= {_lib.NM_MAX_WIDTH}")
+        if len(self.classifier_layers) > _lib.NM_MAX_CLS or any(w < 1 or w > 128 for w in self.classifier_layers):
+            raise ValueError(f"classifier_layers: at most {_lib.NM_MAX_CLS} widths in 1..128, got {list(self.classifier_layers)}")
+        if self.classifier_layers and not (2 <= self.num_classes <= _lib.NM_MAX_CLASSES):
+            raise ValueError(f"num_classes must be 2..{_lib.NM_MAX_CLASSES}")
 
     # encoder / decoder layer sizes exactly as the reference computes them
     def enc_sizes(self, m: int) -> List[int]:
@@ -129,6 +136,16 @@ def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
         for bank in ("health", "disease"):
             for m in range(spec.M):
                 dec(m, bank)
+        if spec.classifier_layers:               # nn.Sequential: Linear 4i, BatchNorm1d 4i+1, ReLU, Dropout; Linear 4n
+            sizes = [spec.latent] + list(spec.classifier_layers)
+            for i in range(len(sizes) - 1):
+                out.append((f"classifier.classifier.{4 * i}.weight", (sizes[i + 1], sizes[i])))
+                out.append((f"classifier.classifier.{4 * i}.bias", (sizes[i + 1],)))
+                for t in ("weight", "bias", "running_mean", "running_var"):
+                    out.append((f"classifier.classifier.{4 * i + 1}.{t}", (sizes[i + 1],)))
+            n = 4 * (len(sizes) - 1)
+            out.append((f"classifier.classifier.{n}.weight", (spec.num_classes, sizes[-1])))
+            out.append((f"classifier.classifier.{n}.bias", (spec.num_classes,)))
     else:
         raise ValueError(f"unknown model kind {spec.kind!r}")
     return out
@@ -191,6 +208,10 @@ class ParamLayout:
             shape = self.shapes[n]
             if n.endswith("logvar_out"):
                 out[n] = torch.full(shape, -3.0)
+            elif len(shape) == 1 and n.endswith((".weight", ".running_var")):      # BatchNorm1d defaults
+                out[n] = torch.ones(shape)
+            elif n.endswith(".running_mean") or (n.endswith(".bias") and n[:-4] + "running_mean" in self.shapes):
+                out[n] = torch.zeros(shape)
             elif n.startswith("alpha_m_list"):
                 out[n] = torch.randn(shape, generator=g)
             elif n.endswith(".weight"):
@@ -221,7 +242,22 @@ class ParamLayout:
         md.alpha = o.get(f"alpha_m_list.{m}", -1) if has_enc else -1
 
     def fill_head(self, job: "_lib.NmJob"):
-        """Offsets of the regression head's tensors (kind == "regression")."""
+        """Offsets of the head tensors: regressor (kind == "regression"), classifier (kind == "endtoend")."""
+        s = self.spec
+        job.cls_layers, job.cls_classes = 0, 0
+        if s.kind == "endtoend" and s.classifier_layers:
+            job.cls_layers, job.cls_classes = len(s.classifier_layers), s.num_classes
+            for i, w in enumerate(s.classifier_layers):
+                job.cls_width[i] = w
+                job.cls_w[i] = self.offsets[f"classifier.classifier.{4 * i}.weight"]
+                job.cls_b[i] = self.offsets[f"classifier.classifier.{4 * i}.bias"]
+                job.cls_bn_w[i] = self.offsets[f"classifier.classifier.{4 * i + 1}.weight"]
+                job.cls_bn_b[i] = self.offsets[f"classifier.classifier.{4 * i + 1}.bias"]
+                job.cls_bn_mean[i] = self.offsets[f"classifier.classifier.{4 * i + 1}.running_mean"]
+                job.cls_bn_var[i] = self.offsets[f"classifier.classifier.{4 * i + 1}.running_var"]
+            n = len(s.classifier_layers)
+            job.cls_w[n] = self.offsets[f"classifier.classifier.{4 * n}.weight"]
+            job.cls_b[n] = self.offsets[f"classifier.classifier.{4 * n}.bias"]
         if self.spec.kind != "regression":
             job.reg_head = 0
             return

@@ -506,7 +506,7 @@ def classifier_fwd(P, spec: Spec, z, training: bool, bn_stats: Optional[dict] = 
     li = 0
     for _ in range(len(spec.classifier_layers)):
         p = f"classifier.classifier.{li}"
-        h = torch.nn.functional.linear(h, P[p + ".weight"], P[p + ".bias"])
+        h = linear(h, P[p + ".weight"], P[p + ".bias"])
         q = f"classifier.classifier.{li + 1}"
         if training:
             h = torch.nn.functional.batch_norm(h, None, None, P[q + ".weight"], P[q + ".bias"], True, 0.1, 1e-5)
@@ -516,7 +516,7 @@ def classifier_fwd(P, spec: Spec, z, training: bool, bn_stats: Optional[dict] = 
         h = torch.relu(h)
         li += 4
     p = f"classifier.classifier.{li}"
-    return torch.nn.functional.linear(h, P[p + ".weight"], P[p + ".bias"])
+    return linear(h, P[p + ".weight"], P[p + ".bias"])
 
 
 def forward_endtoend(P, spec: Spec, xes, cs, eps, training: bool = True, bn_stats=None):

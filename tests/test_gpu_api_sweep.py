@@ -237,12 +237,112 @@ def test_endtoend_model_matches_reference():
         model.optimizer.zero_grad()
         loss["total_loss"].backward()
         model.optimizer.step()
-    ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    sd, wref = model.state_dict(), g.weights(f"w{g.n_steps}")
+    ok, worst = _traj_ok(sd, wref, 1e-4, g.n_steps)
     assert ok, worst
+    for k, v in wref.items():                      # BatchNorm buffers: momentum-0.1 running statistics, batch counter
+        if k.endswith(("running_mean", "running_var")):
+            assert float((sd[k] - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v) == g.n_steps
     model.eval()
     model._eps_override = None
     logits = model.predict([x.to(DEV) for x in g.xs(0)], [g.t("c")[0].to(DEV)] * g.M)
     assert rel_err(logits.cpu(), torch.from_numpy(g.z["predict"])) < 0.1
+
+
+def test_fused_endtoend_training_matches_reference_trajectory():
+    """JobSet.train_endtoend (export launch, classifier-head kernel with its Adam and BatchNorm statistics,
+    trunk launch with d CE / d z and the hinge row coefficients) against the reference class's own 3-step
+    trajectory (golden e2e3: classifier in train mode, dropout 0, margin 1, w_c 1)."""
+    from tests.hip_harness import swap_batch
+    g = Golden("e2e3")
+    layers = [int(v) for v in g.z["layers"]]
+    margin, wc = (float(v) for v in g.z["margin_wc"])
+    spec = nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim, True, "endtoend", tuple(layers), 2)
+    state = {k: v for k, v in g.weights("w0").items() if not k.endswith("num_batches_tracked")}
+    tables = [nm.Table(g.xs(0)[m], g.t("c")[0], DEV) for m in range(g.M)]
+    job = nm.Job(spec, tables, combine="poe", state=state, kl_weight=0.1, ll_weight=0.1, single_bypass=False)
+    job.cls_margin, job.cls_w_contrast, job.cls_dropout = margin, wc, 0.0
+    job.set_eps(g.t("eps")[0])
+    js = nm.JobSet([job])
+    keys = ["total_loss", "recon_loss_health", "recon_loss_disease", "kl_loss", "classification_loss", "contrastive_loss"]
+    for s in range(g.n_steps):
+        if s > 0:
+            swap_batch(job, g, s)
+        job.set_labels(g.t("labels")[s])
+        js.train_endtoend(1)
+        torch.cuda.synchronize()
+        ref = dict(zip(keys, g.z[f"loss{s}"]))
+        row = job.loss_log[0].cpu()
+        assert abs(float(row[13]) - ref["classification_loss"]) <= 2e-2 * ref["classification_loss"], s
+        assert abs(float(row[14]) - ref["contrastive_loss"]) <= 2e-2 * ref["contrastive_loss"] + 1e-3, s
+        assert abs(-float(row[3:3 + g.M].sum()) - ref["recon_loss_health"]) <= 1e-4 * ref["recon_loss_health"], s
+    wref = g.weights(f"w{g.n_steps}")
+    sd = job.state_dict()
+    ok, worst = _traj_ok(sd, wref, 1e-4, g.n_steps)
+    assert ok, worst
+    for k, v in wref.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert float((sd[k] - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, k
+
+
+def test_classifier_head_config5_shape_vs_oracle():
+    """nm_head_classifier at the config-5 shape (Z = 64, classifier [128, 64, 32], ragged batch of 200): logits,
+    cross entropy, hinge, every gradient of the model (classifier weights / BatchNorm affine, and the trunk
+    gradients that receive d CE / d z and the hinge row coefficients) against the oracle with the kernel's
+    operand rounding; eval-mode predict() against the oracle with running statistics."""
+    dims, hidden, Z, cdim, B, layers = [60, 45, 70], [40, 32], 64, 5, 200, [128, 64, 32]
+    torch.manual_seed(9)
+    model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
+                                        dropout_rate=0.0, num_classes=2)
+    model.to(DEV)
+    model.train()
+    g = torch.Generator().manual_seed(21)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.rand(B, cdim, generator=g)
+    labels = (torch.rand(B, generator=g) < 0.4).long()
+    eps = torch.randn(B, Z, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model._eps_override = eps
+    fwd = model.forward([x.to(DEV) for x in xes], [c.to(DEV)] * 3)
+    loss = model.loss_function(xes, fwd, labels.to(DEV), margin=0.5, weightcontrastive=0.7)
+    model.optimizer.zero_grad()
+    loss["total_loss"].backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+    spec = R.Spec(dims, hidden, Z, cdim, True, kind="endtoend", classifier_layers=layers)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        of = R.forward_endtoend(P, spec, xes, [c] * 3, eps, training=True)
+        ol = R.loss_endtoend(spec, xes, of, labels, margin=0.5, weightcontrastive=0.7)
+        ol["total_loss"].backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    assert rel_err(fwd["logits"].cpu(), of["logits"].detach()) < 2e-2
+    for k in ("classification_loss", "contrastive_loss", "total_loss"):
+        assert abs(float(loss[k]) - float(ol[k])) <= 5e-3 * abs(float(ol[k])) + 1e-5, k
+    for k, v in P.items():
+        if v.grad is None or k.endswith(tuple(f"classifier.{4 * i}.bias" for i in range(len(layers)))):
+            continue                                  # Linear biases ahead of BatchNorm: exactly zero gradient in exact arithmetic
+        a, r = got[k].flatten().float(), v.grad.flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+        rl2 = float((a - r).norm() / r.norm())
+        assert cos > 0.99 and rl2 < 0.15, (k, cos, rl2)
+    # eval mode: running statistics (updated once by the train-mode forward above), classifier on the joint mean
+    model.eval()
+    sd1 = model.state_dict()
+    logits = model.predict([x.to(DEV) for x in xes], [c.to(DEV)] * 3)
+    bn = {k: v for k, v in sd1.items() if "running" in k}
+    P1 = {k: v.clone() for k, v in sd1.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        of1 = R.forward_endtoend(P1, spec, xes, [c] * 3, eps, training=False, bn_stats=bn)
+        ref_logits = R.classifier_fwd(P1, spec, of1["mu"], False, bn)
+    finally:
+        R.set_operand_rounding("fp32")
+    assert rel_err(logits.cpu(), ref_logits) < 2e-2
 
 
 def _metric_sets():
