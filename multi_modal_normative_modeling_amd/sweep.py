@@ -225,3 +225,67 @@ def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[in
         results.append({"fold": k, "steps_per_s": sps, "final_total": float(j.loss_log[last, 0]),
                         "final_mse": float(j.loss_log[last, 12]), **scores})
     return results
+
+
+def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int], n_folds: int, epochs: int, device,
+                       modalities: Sequence[str] = prep.HCP_MODALITIES, latent: int = 64,
+                       classifier_layers: Sequence[int] = (128, 64, 32), dropout_rate: float = 0.5, margin: float = 1.0,
+                       weightcontrastive: float = 0.1, lr: float = 1e-4, hc_label: int = 1):
+    """multimodal_kfold_cvae_nmpmcont.py:180-320 for the given folds, all folds training concurrently:
+    cVAE_multimodal_endtoend (shared encoders, PoE, health / disease decoder banks, classifier on z) on
+    RobustScaler-ed tables with the 29 one-hot covariates and labels healthy = 0 / disease = 1 (:118), batches in
+    table order (shuffle=False, :213); then evaluate() (:29-70) on the held-out fold -- eval mode, classifier on
+    the joint mean, argmax -- with the confusion metrics computed on the device.  The cyclic learning-rate
+    arithmetic of :266-270 is inert in the reference (it assigns an attribute the optimizer never reads), so
+    the optimizer runs at its constructor lr here as there."""
+    folds = prep.kfold_indices(len(cohort.iid), n_folds, 42)
+    labels_all = (cohort.dia != hc_label).astype(np.int32)
+    jobs, scalers = [], []
+    for k in folds_to_run:
+        tr = folds[k][0]
+        xs, sc = [], []
+        for m in modalities:
+            center, scale = prep.robust_scaler_fit(cohort.x[m][tr])
+            xs.append(prep.robust_scaler_transform(cohort.x[m][tr], center, scale).astype(np.float32))
+            sc.append((center, scale))
+        scalers.append(sc)
+        cov = prep.one_hot_covariates(cohort.age[tr], cohort.gender[tr])
+        tables = [Table(x, cov, device) for x in xs]
+        spec = ModelSpec([t.D for t in tables], list(workload.HIDDEN), latent, workload.C_DIM, True, "endtoend",
+                         tuple(classifier_layers), 2)
+        j = Job(spec, tables, combine="poe", lr=lr, kl_weight=0.1, ll_weight=0.1, seed=1000 * k, init_seed=42 + k,
+                loss_cap=8, single_bypass=False)
+        j.cls_dropout, j.cls_margin, j.cls_w_contrast = float(dropout_rate), float(margin), float(weightcontrastive)
+        j.set_labels(labels_all[tr])
+        jobs.append(j)
+    js = JobSet(jobs)
+    n = epochs * jobs[0].batches_per_epoch
+    t0 = time.perf_counter()
+    js.train_endtoend(n)
+    torch.cuda.synchronize(device)
+    sps = n * len(jobs) / max(time.perf_counter() - t0, 1e-9)
+    preds, labs, finals = [], [], []
+    for k, j, sc in zip(folds_to_run, jobs, scalers):
+        te = folds[k][1]
+        xs = [prep.robust_scaler_transform(cohort.x[m][te], *sc[i]).astype(np.float32) for i, m in enumerate(modalities)]
+        cov = prep.one_hot_covariates(cohort.age[te], cohort.gender[te])           # re-binned on the test rows (:203-209)
+        tables = [Table(x, cov, device) for x in xs]
+        ev = Job(j.spec, tables, combine="poe", state=j.state_dict(), seed=j.seed + 17, single_bypass=False,
+                 n_tiles_ws=tables[0].n_tiles)
+        ev.cls_train, ev.cls_use_mu = False, True                                   # model.eval(); predict(): classifier(mu)
+        ev.enable_exports(loc=False, sqerr=False, rowdev=False, latent=True)
+        es = JobSet([ev])
+        es.forward()
+        es.head_classifier(backward=False, tile0=0, n_tiles=tables[0].n_tiles)
+        preds.append(torch.argmax(ev.out_logits[: len(te), :2], dim=1).to(torch.int32))
+        labs.append(torch.as_tensor(labels_all[te]))
+        last = (j.step - 1) % j.loss_cap
+        finals.append([float(v) for v in j.loss_log[last, [0, 13, 14]]])
+    cm = metrics.confusion_metrics(preds, labs, device=device).cpu()
+    out = []
+    for i, k in enumerate(folds_to_run):
+        row = {"fold": k, "steps_per_s": sps, "final_trunk_total": finals[i][0], "final_ce": finals[i][1],
+               "final_contrastive": finals[i][2]}
+        row.update({name: float(cm[i, c]) for c, name in enumerate(metrics.CONFUSION_COLUMNS)})
+        out.append(row)
+    return out
