@@ -351,6 +351,66 @@ __device__ __forceinline__ void xchunk_store(const Ctx& c, const XStage& s, __bf
   }
 }
 
+// ---- LDS-staged weight tiles ---------------------------------------------------------------------
+// A block of up to 128 weight rows is contiguous in the flat buffer (row pitch = kpitch(K)), so the workgroup
+// copies it with perfectly coalesced 16-byte loads (piece p = thread + j * WG <-> floats [4p, 4p+4)), converts
+// to bf16 and lays it out [128][ld] in LDS; the MFMA A-fragments are then ds_read_b128 like the activations.
+// Rows >= nrows and the columns [Kp, wcols) are written as zeros (finite operands for the padded lanes).
+constexpr int WPIECES = (128 * 128 / 4) / WG;      // 16-byte pieces per thread for a full 128 x 128 block
+struct WStage { f32x4 v[WPIECES]; };
+__device__ __forceinline__ void wstage_load(const Ctx& c, WStage& s, gcf32 W, int npieces) {
+#pragma unroll
+  for (int j = 0; j < WPIECES; ++j) s.v[j] = *(const GAS f32x4*)(W + 4 * min(c.tid + j * WG, npieces - 1));
+}
+__device__ __forceinline__ void wstage_store(const Ctx& c, const WStage& s, __bf16* dst, int ld, int Kp, int wcols,
+                                             int npieces) {
+  const int kp4 = Kp >> 2;
+  const float rk = 1.0f / (float)kp4;
+#pragma unroll
+  for (int j = 0; j < WPIECES; ++j) {
+    const int p = c.tid + j * WG;
+    const int row = idiv(p, kp4, rk), col = (p - row * kp4) * 4;
+    if (row < 128) {
+      bf16x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(p < npieces ? s.v[j][i] : 0.f);
+      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = pk;
+    }
+  }
+  const int padc = wcols - Kp;                      // 0 .. 32, a multiple of 8
+  if (padc > 0) {
+    const int pp = padc >> 2;
+    const float rp = 1.0f / (float)pp;
+    for (int e = c.tid; e < 128 * pp; e += WG) {
+      const int row = idiv(e, pp, rp), col = Kp + (e - row * pp) * 4;
+      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    }
+  }
+}
+
+// 64-column chunk kc of the first encoder layer's weights [N][Kp]: 16 pieces of 16 bytes per row, 256
+// contiguous bytes per row; bf16 [128][LDX] in LDS, zeros for rows >= N and columns >= Kp.
+constexpr int W0PIECES = (128 * XCH / 4) / WG;
+struct W0Stage { f32x4 v[W0PIECES]; };
+__device__ __forceinline__ void w0chunk_load(const Ctx& c, W0Stage& s, gcf32 W, int N, int Kp, int kc) {
+#pragma unroll
+  for (int j = 0; j < W0PIECES; ++j) {
+    const int p = c.tid + j * WG, row = p >> 4, col = kc * XCH + (p & 15) * 4;
+    s.v[j] = *(const GAS f32x4*)(W + (int64_t)min(row, N - 1) * Kp + min(col, Kp - 4));
+  }
+}
+__device__ __forceinline__ void w0chunk_store(const Ctx& c, const W0Stage& s, __bf16* dst, int N, int Kp, int kc) {
+#pragma unroll
+  for (int j = 0; j < W0PIECES; ++j) {
+    const int p = c.tid + j * WG, row = p >> 4, col = kc * XCH + (p & 15) * 4;
+    const bool ok = row < N && col < Kp;
+    bf16x4 pk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(ok ? s.v[j][i] : 0.f);
+    *reinterpret_cast<bf16x4*>(dst + row * LDX + (p & 15) * 4) = pk;
+  }
+}
+
 // [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer.  Two branch-free
 // passes (clamped, unconditional loads): the covariate/ones/pad columns from the packed table (its
 // columns D .. D+C hold c | 1), then the z columns from the latent workspace.
@@ -424,24 +484,26 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
   relaunder(c);
   const int ksteps = wpad(K) / 32;       // <= 4
   const int ntn = wpad(N) / 16;
-  // every weight fragment of the layer first: 16 x 16-byte loads in flight per lane
-  bf16x8 wf[4][2];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      wf[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+  const int Kp = kpitch(K), npieces = N * (Kp >> 2);
+  // the layer's weights: coalesced global -> registers -> bf16 tile in Q (free during the forward chain)
+  WStage wsg;
+  wstage_load(c, wsg, W, npieces);
   tr(c, 0);
   f32x4 acc[2][RT];
   bias_acc(c, acc, b, N, 0);
+  wstage_store(c, wsg, c.Q, LDP, Kp, wpad(K), npieces);
+  lds_barrier();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     if (ks < ksteps) {
+      bf16x8 wf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.Q, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ks][t], a, acc[t][rt]);
+        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
       }
     }
   }
@@ -464,47 +526,39 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
   const int Kx = md.Kx;
   const int nch = (Kx + XCH - 1) / XCH;
   const int ntn = wpad(N) / 16;
+  const int Kp = kpitch(K);
+  __bf16* Wq = c.Q + ROWS * LDX;          // [128][LDX] weight chunk behind the [256][LDX] x chunk
   f32x4 acc[2][RT];
   bias_acc(c, acc, b, N, 0);
   XStage st;
-  bf16x8 wf[2][2];
+  W0Stage wst;
   xchunk_load(c, st, asg(md.xb), Kx, 0);
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) wf[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+  w0chunk_load(c, wst, W, N, Kp, 0);
   tr(c, 6);
   for (int kc = 0; kc < nch; ++kc) {
     xchunk_store(c, st, c.Q);
+    w0chunk_store(c, wst, Wq, N, Kp, kc);
     tr(c, 7);
     lds_barrier();
     tr(c, 8);
-    bf16x8 wn[2][2];
     if (kc + 1 < nch) {                   // next chunk's inputs and weights fly during this chunk's MFMAs
       xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          wn[ks][t] = w_frag(W, N, K, (c.wn + 4 * t) * 16 + c.c16, (kc + 1) * XCH + ks * 32 + 8 * c.g);
+      w0chunk_load(c, wst, W, N, Kp, kc + 1);
     }
     tr(c, 9);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (kc * XCH + ks * 32 < Kx) {
+        bf16x8 wf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[t] = lds_frag(Wq, LDX, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           bf16x8 a = lds_frag(c.Q, LDX, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ks][t], a, acc[t][rt]);
+          for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
         }
       }
-    }
-    if (kc + 1 < nch) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wf[ks][t] = wn[ks][t];
     }
     tr(c, 10);
     lds_barrier();
@@ -992,19 +1046,15 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const int valid = min(PW, D - d0);
       tr(c, 16);
       if (c.tid < PW) c.colacc[c.tid] = 0.f;
-      lds_barrier();
-      tr(c, 17);
       // x_hat chunk: acc[d][r]
       {
         const int ksteps = wpad(Hl) / 32;
-        // everything this chunk reads from memory is requested first: weight fragments, the fp32
-        // inputs of the residual (rows are always inside the zero-padded table) and logvar_out
-        bf16x8 wf[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            wf[ks][t] = w_frag(Wo, D, Hl, d0 + (c.wn + 4 * t) * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+        // everything this chunk reads from memory is requested first: the chunk's weight rows (contiguous:
+        // coalesced copy into a bf16 tile in Q, free until the epilogue), the fp32 inputs of the residual
+        // (rows are always inside the zero-padded table) and logvar_out
+        const int Kpo = kpitch(Hl), wpieces = valid * (Kpo >> 2);
+        WStage wsg;
+        wstage_load(c, wsg, Wo + (int64_t)d0 * Kpo, wpieces);
         f32x4 xin[RT];                     // inputs of feature tile t = 0 now, t = 1 after tile 0's epilogue
         float sv[2][4];
 #pragma unroll
@@ -1023,17 +1073,24 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         tr(c, 18);
         f32x4 acc[2][RT];
         bias_acc(c, acc, bo, D, d0);
+        wstage_store(c, wsg, c.Q, LDP, Kpo, wpad(Hl), wpieces);
+        lds_barrier();
+        tr(c, 17);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           if (ks < ksteps) {
+            bf16x8 wf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.Q, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
               bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
-              for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[ks][t], a, acc[t][rt]);
+              for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
             }
           }
         }
+        lds_barrier();                     // the weight tile is fully read: the epilogue (delta) or the next chunk's tile may overwrite Q
         prof(c, PH_X_MFMA);
         tr(c, 19);
         // epilogue: residual, NLL, d logvar_out, delta chunk -> Q.  Lane: 4 consecutive ROI of one row.
