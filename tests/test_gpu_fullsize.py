@@ -141,3 +141,91 @@ def test_properties_full_size():
     torch.cuda.synchronize()
     assert torch.equal(jobs[0].params.cpu(), jobs[1].params.cpu())
     assert torch.isfinite(jobs[0].loss_log[:8]).all()
+
+
+def _grad_check(got, P, skip=()):
+    for k, v in P.items():
+        if v.grad is None or k.endswith(skip):
+            continue
+        a, r = got[k].flatten().float(), v.grad.flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+        rl2 = float((a - r).norm() / r.norm())
+        assert cos > 0.99 and rl2 < 0.15, (k, cos, rl2)
+
+
+def test_config5_full_model_with_classifier_head():
+    """BASELINE config 5 at full size (3 x 379 ROI, c = 29, H = [110, 110], Z = 64, classifier [128, 64, 32],
+    batch 256): trunk + classifier head kernels against the oracle with the kernels' operand rounding, and the
+    reconstruction losses against the fp32 oracle at the north-star bound."""
+    dims, hidden, Z, cdim, B, layers = [379, 379, 379], [110, 110], 64, 29, 256, [128, 64, 32]
+    torch.manual_seed(3)
+    model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
+                                        dropout_rate=0.0, num_classes=2)
+    model.to(DEV)
+    model.train()
+    g = torch.Generator().manual_seed(33)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    c = onehot(g, B, cdim)
+    labels = (torch.rand(B, generator=g) < 0.4).long()
+    eps = torch.randn(B, Z, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model._eps_override = eps
+    fwd = model.forward([x.to(DEV) for x in xes], [c.to(DEV)] * 3)
+    loss = model.loss_function(xes, fwd, labels.to(DEV), margin=1.0, weightcontrastive=0.1)
+    model.optimizer.zero_grad()
+    loss["total_loss"].backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    spec = R.Spec(dims, hidden, Z, cdim, True, kind="endtoend", classifier_layers=layers)
+    ref = {}
+    for mode in ("fp32", "bf16"):
+        P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd0.items()}
+        R.set_operand_rounding(mode)
+        try:
+            of = R.forward_endtoend(P, spec, xes, [c] * 3, eps, training=True)
+            ol = R.loss_endtoend(spec, xes, of, labels, margin=1.0, weightcontrastive=0.1)
+            ol["total_loss"].backward()
+        finally:
+            R.set_operand_rounding("fp32")
+        ref[mode] = (of, ol, P)
+    for k in ("recon_loss_health", "recon_loss_disease"):
+        assert abs(float(loss[k]) - float(ref["fp32"][1][k])) <= 1e-4 * float(ref["fp32"][1][k]), k       # north-star bound
+    for k in ("classification_loss", "contrastive_loss", "total_loss", "kl_loss"):
+        assert abs(float(loss[k]) - float(ref["bf16"][1][k])) <= 5e-3 * abs(float(ref["bf16"][1][k])) + 1e-5, k
+    _grad_check(got, ref["bf16"][2], skip=tuple(f"classifier.{4 * i}.bias" for i in range(len(layers))))
+
+
+def test_regression_model_full_size_with_head():
+    """cVAE_multimodal_regression at 3 x 379 ROI (1137 concatenated residual columns = 9 chunks of the head kernel),
+    raw 2-column covariates, batch 256: losses and every gradient against the oracle."""
+    dims, hidden, Z, cdim, B = [379, 379, 379], [110, 110], 10, 2, 256
+    torch.manual_seed(4)
+    model = nm.cVAE_multimodal_regression(dims, hidden, Z, cdim, learning_rate=1e-4, modalities=3, non_linear=True)
+    model.to(DEV)
+    g = torch.Generator().manual_seed(44)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.stack([torch.randint(22, 37, (B,), generator=g).float(), torch.randint(0, 2, (B,), generator=g).float()], dim=1)
+    fi = torch.randn(B, 1, generator=g) * 0.5 + 1.0
+    eps = torch.randn(B, Z, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model._eps_override = eps
+    out = model.forward_multimodal([x.to(DEV) for x in xes], [c.to(DEV)] * 3, "gpoe")
+    losses = model.loss_function_multimodal(xes, out, fi.to(DEV), lambda_reg=1.0)
+    model.optimizer1.zero_grad()
+    losses["total"].backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    spec = R.Spec(dims, hidden, Z, cdim, True, kind="regression")
+    ref = {}
+    for mode in ("fp32", "bf16"):
+        P = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        R.set_operand_rounding(mode)
+        try:
+            fw = R.forward_regression(P, spec, xes, [c] * 3, "gpoe", eps)
+            lo = R.loss_regression(spec, xes, fw, fi, lambda_reg=1.0)
+            lo["total"].backward()
+        finally:
+            R.set_operand_rounding("fp32")
+        ref[mode] = (fw, lo, P)
+    ll32 = float(ref["fp32"][1]["ll"])
+    assert abs(float(losses["ll"]) - ll32) <= 1e-4 * abs(ll32)                                              # north-star bound
+    assert abs(float(losses["regression"]) - float(ref["bf16"][1]["regression"])) <= 5e-3 * float(ref["bf16"][1]["regression"])
+    _grad_check(got, ref["bf16"][2])
