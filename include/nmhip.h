@@ -71,8 +71,8 @@ typedef struct nm_modality {
   int64_t out_w, out_b;                           /* decoder_mean_layer                   */
   int64_t alpha;                                  /* alpha_m_list.{m} or -1               */
   /* optional per-row exports (NM_F_EXPORT), indexed by absolute table row; may be NULL */
-  float* out_loc;         /* [rows_alloc][D]  decoder mean x_hat                         */
-  float* out_sqerr;       /* [rows_alloc][D]  (x - x_hat)^2                              */
+  float* out_loc;         /* [rows_alloc][x_pitch]  decoder mean x_hat (pad columns 0)   */
+  float* out_sqerr;       /* [rows_alloc][x_pitch]  (x - x_hat)^2        (pad columns 0)   */
   float* out_rowdev;      /* [rows_alloc]     sum_d (x - x_hat)^2 / D                    */
   /* optional extra loss gradient on the reconstruction, d L_extra / d x_hat, [rows_alloc][x_pitch]
    * (regression head cVAE.py:2309-2346, contrastive hinge cVAE.py:2140-2200); added to the NLL term */

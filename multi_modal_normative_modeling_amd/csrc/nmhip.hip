@@ -1146,19 +1146,25 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             nll_part += dv ? hq + (float)nvalid * (0.5f * sv[t][i] + LOG_SQRT_2PI) : 0.f;
             colsum[i] = dv ? 0.5f * (float)nvalid - hq : 0.f;
           }
-          if (exportf) {
+          if (exportf && dg0 < xp) {           // exports share the fp32 table's row pitch: one 16-byte store each
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
               const int r = c.wm * WROWS + rt * 16 + c.c16;
+              if (r < c.nrows) {
+                f32x4 lo, sq;
+                float rs = 0.f;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (r < c.nrows && dg0 + i < D) {
+                for (int i = 0; i < 4; ++i) {
+                  const bool dv = dg0 + i < D;
                   const float xh = acc[t][rt][i], diff = xh - xcur[rt][i];
-                  int64_t gi = (int64_t)(c.row0 + r) * D + dg0 + i;
-                  if (md.out_loc) asg(md.out_loc)[gi] = xh;
-                  if (md.out_sqerr) asg(md.out_sqerr)[gi] = diff * diff;
-                  if (md.out_rowdev) atomicAdd(&c.rowacc[r], diff * diff);
+                  lo[i] = dv ? xh : 0.f;
+                  sq[i] = dv ? diff * diff : 0.f;
+                  rs += sq[i];
                 }
+                const int64_t gi = (int64_t)(c.row0 + r) * xp + dg0;
+                if (md.out_loc) *(GAS f32x4*)(asg(md.out_loc) + gi) = lo;
+                if (md.out_sqerr) *(GAS f32x4*)(asg(md.out_sqerr) + gi) = sq;
+                if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
               }
             }
           }
@@ -1453,18 +1459,38 @@ __device__ __forceinline__ CatCol cat_col(const nm_job_t* J, int M, int col) {
   }
   return r;
 }
-// Q[r][j] = x[r][col] - x_hat[r][col] for concatenated column col = k0 + j < SD, valid rows; 0 elsewhere
+// Q[r][j] = x[r][col] - x_hat[r][col] for concatenated column col = k0 + j < SD, valid rows; 0 elsewhere.
+// Walked per modality segment in the modality's own column space: x_f32 and the exported x_hat share the
+// row pitch x_pitch (a multiple of 4), so a group of four columns is two aligned 16-byte loads.
 __device__ __forceinline__ void resid_chunk_to_Q(const Ctx& c, int M, int SD, int k0) {
   const nm_job_t* J = c.job;
-  const int j = c.tid & (PW - 1);               // WG is a multiple of PW: a thread keeps its column
-  const bool cv = k0 + j < SD;
-  const CatCol cc = cat_col(J, M, min(k0 + j, SD - 1));
-  const nm_modality_t& md = J->mod[cc.m];
-  gcf32 xf = asg(md.x_f32);
-  gcf32 xh = asg((const float*)md.out_loc);
-  for (int r = c.tid >> 7; r < ROWS; r += WG / PW) {
-    float v = xf[(int64_t)(c.row0 + r) * md.x_pitch + cc.d] - xh[(int64_t)(c.row0 + r) * md.D + cc.d];
-    c.Q[r * LDP + j] = (__bf16)((cv && r < c.nrows) ? v : 0.f);
+  int koff = 0;
+  for (int m = 0; m < M; ++m) {
+    const nm_modality_t& md = J->mod[m];
+    const int lo = max(0, k0 - koff), hi = min(md.D, k0 + PW - koff);     // this modality's columns inside the chunk
+    if (lo < hi) {
+      gcf32 xf = asg(md.x_f32);
+      gcf32 xh = asg((const float*)md.out_loc);
+      const int g0 = lo >> 2, ng = ((hi + 3) >> 2) - g0;
+      const float rng = 1.0f / (float)ng;
+      for (int e = c.tid; e < ROWS * ng; e += WG) {
+        const int r = idiv(e, ng, rng), d0 = 4 * (g0 + e - r * ng);
+        const int64_t o = (int64_t)(c.row0 + r) * md.x_pitch + d0;
+        const f32x4 xv = *(const GAS f32x4*)(xf + o), hv = *(const GAS f32x4*)(xh + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (d0 + i >= lo && d0 + i < hi) c.Q[r * LDP + koff + d0 + i - k0] = (__bf16)(r < c.nrows ? xv[i] - hv[i] : 0.f);
+      }
+    }
+    koff += md.D;
+  }
+  if (k0 + PW > SD) {                             // columns past the end of the concatenation
+    const int z0 = SD - k0, nz = PW - z0;
+    const float rz = 1.0f / (float)nz;
+    for (int e = c.tid; e < ROWS * nz; e += WG) {
+      const int r = idiv(e, nz, rz);
+      c.Q[r * LDP + z0 + (e - r * nz)] = (__bf16)0.0f;
+    }
   }
 }
 // P[r][f] = relu(acc) for f < N (N a multiple of 16, <= 128)
@@ -1512,7 +1538,11 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   gcf32 W1 = prm + J->reg_w[0], b1 = prm + J->reg_b[0], W2 = prm + J->reg_w[1], b2 = prm + J->reg_b[1];
   gcf32 W3 = prm + J->reg_w[2];
   const WsLayout wl = ws_layout(J->M, J->L, J->Z);
-  gbf16 ws_h1 = (gbf16)(c.ws + wl.zc);          // the trunk's workspace is dead between its two launches
+  // the trunk's workspace is dead between its two launches: h1 first, then the residual chunks (bf16), kept for
+  // the backward pass so that x / x_hat are read once
+  gbf16 ws_h1 = (gbf16)c.ws;
+  gbf16 ws_res = (gbf16)(c.ws + (int64_t)ROWS * PW * 2);
+  (void)wl;
   const int nch = (SD + PW - 1) / PW;
 
   // ---- layer 1: h1 = relu(W1 resid + b1), the residual streamed through Q ----
@@ -1523,6 +1553,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
     const int k0 = ch * PW, valid = min(PW, SD - k0), ksteps = rup(valid, 32) / 32;
     resid_chunk_to_Q(c, M, SD, k0);
     lds_barrier();
+    if (bwd) store_act(c, ws_res + (int64_t)ch * ROWS * PW, c.Q, PW);
     for (int ks = 0; ks < ksteps; ++ks) {
       bf16x8 wf[2];
 #pragma unroll
@@ -1628,7 +1659,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   for (int ch = 0; ch < nch; ++ch) {
     relaunder(c);
     const int k0 = ch * PW, valid = min(PW, SD - k0);
-    resid_chunk_to_Q(c, M, SD, k0);
+    load_act(c, c.Q, ws_res + (int64_t)ch * ROWS * PW, PW);
     lds_barrier();
     zero_acc(acc);
     for (int s = 0; s < N1 / 32; ++s) {
@@ -2244,6 +2275,12 @@ int nm_validate_job(const nm_job_t* j) {
 int64_t nm_workspace_bytes(const nm_job_t* j) {
   if (!j) return -1;
   int64_t b = ws_layout(j->M, j->L, j->Z).total;
+  if (j->reg_head) {                      // regression head: h1 + one bf16 tile per 128 concatenated residual columns
+    int sd = 0;
+    for (int m = 0; m < (j->M_enc > 0 ? j->M_enc : j->M); ++m) sd += j->mod[m].D;
+    int64_t hb = (int64_t)(1 + (sd + PW - 1) / PW) * ROWS * PW * 2;
+    b = b > hb ? b : (hb + 255) / 256 * 256;
+  }
   if (j->cls_layers > 0 || j->cls_classes > 0) b = b > cls_ws_bytes() ? b : (cls_ws_bytes() + 255) / 256 * 256;
   return b;
 }

@@ -138,6 +138,9 @@ class Job:
         probe = _lib.NmJob()
         probe.M, probe.L, probe.Z = len(self.kmods), len(self.spec.hidden), self.spec.latent
         probe.cls_layers, probe.cls_classes = len(self.spec.classifier_layers), (self.spec.num_classes if self.spec.classifier_layers else 0)
+        probe.reg_head = 1 if self.spec.kind == "regression" else 0
+        for k, (m, _, _) in enumerate(self.kmods):
+            probe.mod[k].D = self.tables[m].D
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
@@ -219,8 +222,9 @@ class Job:
             self.out_logits = torch.zeros(ra, _lib.NM_MAX_CLASSES, device=self.device)
         for j, (m, _, _) in enumerate(self.kmods):
             t = self.tables[m]
-            self.out_loc[j] = torch.zeros(ra, t.D, device=self.device) if loc else None
-            self.out_sqerr[j] = torch.zeros(ra, t.D, device=self.device) if sqerr else None
+            # storage rows share the fp32 table's pitch (16-byte stores in the kernel); the views are [rows, D]
+            self.out_loc[j] = torch.zeros(ra, t.x_pitch, device=self.device)[:, :t.D] if loc else None
+            self.out_sqerr[j] = torch.zeros(ra, t.x_pitch, device=self.device)[:, :t.D] if sqerr else None
             self.out_rowdev[j] = torch.zeros(ra, device=self.device) if rowdev else None
 
     # -- descriptor ----------------------------------------------------------------------------
