@@ -121,16 +121,21 @@ enum { PH_ENC_L0 = 0, PH_ENC_REST, PH_HEADS, PH_LATENT, PH_DEC_ZC, PH_DEC_HID, P
        PH_OUT_WGRAD, PH_NLL_RED, PH_DEC_FINISH, PH_DEC_LOAD, PH_DEC_DGRAD, PH_DEC_WGRAD, PH_DEC_DELTA, PH_ALPHA,
        PH_ENCB_PREP, PH_ENCB_HEADS_DGRAD, PH_ENCB_HEADS_WGRAD, PH_ENCB_LOAD, PH_ENCB_DGRAD, PH_ENCB_WGRAD,
        PH_ENCB_DELTA, PH_ENCB_L0_WGRAD, PH_X_LOADS, PH_X_MFMA, PH_X_EPI, PH_COUNT };
+// Both timers branch on wave-uniform conditions only and let every lane of the wave do the same
+// read-modify-write (same address, same value): a lane-divergent `if (lane == 0)` here would put dozens of
+// EXEC-masked regions into the kernel, and register spills next to such regions are not safe with this
+// compiler (tools/check_spill_exec.py).
 __device__ __forceinline__ void tr(const Ctx& c, int tag) {
-  if ((c.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) {
+  if ((c.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0) {
     unsigned long long t = clock64();
-    int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     nm_trace_cycles[w][tag] += t - c.tlast[w];
     c.tlast[w] = t;
   }
 }
 __device__ __forceinline__ void prof(Ctx& c, int phase) {
-  if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 &&
+      __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
     unsigned long long t = clock64();
     nm_prof_cycles[phase] += t - c.t_last;
     c.t_last = t;
@@ -382,6 +387,38 @@ __device__ __forceinline__ void wstage_store(const Ctx& c, const WStage& s, __bf
     const int pp = padc >> 2;
     const float rp = 1.0f / (float)pp;
     for (int e = c.tid; e < 128 * pp; e += WG) {
+      const int row = idiv(e, pp, rp), col = Kp + (e - row * pp) * 4;
+      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    }
+  }
+}
+
+// Half tile: up to 64 weight rows into a [64][ld] bf16 tile (the 17 KB gradient slab doubles as its home).
+constexpr int HPIECES = (64 * 128 / 4) / WG;
+struct WHalf { f32x4 v[HPIECES]; };
+__device__ __forceinline__ void whalf_load(const Ctx& c, WHalf& s, gcf32 W, int npieces) {
+#pragma unroll
+  for (int j = 0; j < HPIECES; ++j) s.v[j] = *(const GAS f32x4*)(W + 4 * min(c.tid + j * WG, max(npieces, 1) - 1));
+}
+__device__ __forceinline__ void whalf_store(const Ctx& c, const WHalf& s, __bf16* dst, int ld, int Kp, int wcols, int npieces) {
+  const int kp4 = Kp >> 2;
+  const float rk = 1.0f / (float)kp4;
+#pragma unroll
+  for (int j = 0; j < HPIECES; ++j) {
+    const int p = c.tid + j * WG;
+    const int row = idiv(p, kp4, rk), col = (p - row * kp4) * 4;
+    if (row < 64) {
+      bf16x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(p < npieces ? s.v[j][i] : 0.f);
+      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = pk;
+    }
+  }
+  const int padc = wcols - Kp;
+  if (padc > 0) {
+    const int pp = padc >> 2;
+    const float rp = 1.0f / (float)pp;
+    for (int e = c.tid; e < 64 * pp; e += WG) {
       const int row = idiv(e, pp, rp), col = Kp + (e - row * pp) * 4;
       *reinterpret_cast<bf16x4*>(dst + row * ld + col) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     }
@@ -645,6 +682,41 @@ __device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][RT], co
       }
     }
   }
+}
+
+// dgrad with the weights taken from an LDS tile T[n][k] (bf16, row pitch ld) through the transposing read:
+// lane (c16, g) gets T[s*32 + 8g + j][ktile*16 + c16], j = 0..7 -- the fragment the 8 strided dword loads of
+// w_frag_t assemble from global memory.  A = delta rows in LDS, column n_col0 + s*32 onwards.
+__device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], const __bf16* A, int n_col0, const __bf16* T,
+                                           int ld, int nsteps) {
+  for (int s = 0; s < nsteps; ++s) {
+    bf16x4 l0, h0, l1, h1;
+    const unsigned a0 = tr_addr(T, ld, s * 32, (c.wn + 0) * 16, c.lane), a1 = tr_addr(T, ld, s * 32, (c.wn + 4) * 16, c.lane);
+    const unsigned r4 = 4u * ld * 2u;
+    NM_TR_READ(l0, a0, 0); NM_TR_READ(h0, a0 + r4, 0);
+    NM_TR_READ(l1, a1, 0); NM_TR_READ(h1, a1 + r4, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
+    const bf16x8 wf0 = join4(l0, h0), wf1 = join4(l1, h1);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      bf16x8 a = lds_frag(A, LDP, c.wm * WROWS + rt * 16 + c.c16, n_col0 + s * 32 + 8 * c.g);
+      acc[0][rt] = mfma(wf0, a, acc[0][rt]);
+      acc[1][rt] = mfma(wf1, a, acc[1][rt]);
+    }
+  }
+}
+// Hidden-layer dgrad: stage W[N][K] in Q (coalesced copy, as in the forward pass), then dgrad_tile.  On return
+// the tile is still being read by other waves: the caller puts a barrier before reusing Q.
+__device__ __forceinline__ void dgrad_staged(const Ctx& cc, f32x4 (&acc)[2][RT], const __bf16* A, gcf32 W, int N, int K) {
+  Ctx c = cc;
+  relaunder(c);
+  const int Kp = kpitch(K), npieces = N * (Kp >> 2);
+  WStage wsg;
+  wstage_load(c, wsg, W, npieces);
+  tr(c, 33);
+  wstage_store(c, wsg, c.Q, LDP, Kp, wpad(K), npieces);
+  lds_barrier();
+  dgrad_tile(c, acc, A, 0, c.Q, LDP, wpad(N) / 32);
 }
 
 // dgrad through the two encoder heads: P columns [0,Zs) = d mu, [Zs,2Zs) = d logvar
@@ -1040,6 +1112,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     float nll_part = 0.f;
     if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
     const int nchunks = (D + PW - 1) / PW;
+    // read once, outside the per-lane selects below: a descriptor load inside `cond ? load * x : 0` becomes a
+    // lane-divergent branch, and register spills placed around such branches are not safe with this compiler
+    // (tools/check_spill_exec.py)
+    const float llw_b = J->ll_weight * c.inv_b;
     for (int ch = 0; ch < nchunks; ++ch) {
       relaunder(c);
       const int d0 = ch * PW;
@@ -1106,7 +1182,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           for (int i = 0; i < 4; ++i) {
             inv[i] = expf(-sv[t][i]);
             colq[i] = 0.f;
-            coef[i] = (dg0 + i < D) ? J->ll_weight * inv[i] * c.inv_b : 0.f;     // d total / d x_hat = coef * diff
+            coef[i] = (dg0 + i < D) ? llw_b * inv[i] : 0.f;                      // d total / d x_hat = coef * diff
           }
           f32x4 xcur[RT];
 #pragma unroll
@@ -1184,16 +1260,32 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       prof(c, PH_X_EPI);
       tr(c, 20);
       if (!bwd) continue;
-      lds_barrier();
+      // dgrad into the last hidden activation: accg[k][r] += sum_d Q[r][d] Wo[d0 + d][k].  The chunk's weight
+      // rows come back from L2 (the forward tile was copied from them) as two 64-row half tiles through the
+      // gradient slab, read with the transposing LDS load; both halves are requested now.
+      relaunder(c);
+      __bf16* Th = reinterpret_cast<__bf16*>(c.stage);
+      const int Kph = kpitch(Hl), kp4h = Kph >> 2;
+      const int rows_a = min(valid, 64), rows_b = valid - rows_a;
+      WHalf ha, hb;
+      whalf_load(c, ha, Wo + (int64_t)d0 * Kph, rows_a * kp4h);
+      whalf_load(c, hb, Wo + (int64_t)(d0 + (rows_b > 0 ? 64 : 0)) * Kph, rows_b * kp4h);   // never past the tensor
+      whalf_store(c, ha, Th, LDP, Kph, wpad(Hl), rows_a * kp4h);
+      lds_barrier();                              // delta chunk in Q and half tile A complete
       tr(c, 21);
       prof(c, PH_OUT_GEMM);
       // d logvar_out for this chunk
       if (c.tid < valid) apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b);
       prof(c, PH_OUT_DLV);
-      // dgrad into the last hidden activation: accg[k][r] += sum_d Q[r][d] Wo[d0 + d][k]
-      dgrad_acc(c, accg, c.Q, Wo, D, Hl, rup(valid, 32) / 32, d0);
+      dgrad_tile(c, accg, c.Q, 0, Th, LDP, rup(rows_a, 32) / 32);
+      if (rows_b > 0) {
+        lds_barrier();                            // half A fully read
+        whalf_store(c, hb, Th, LDP, Kph, wpad(Hl), rows_b * kp4h);
+        lds_barrier();
+        dgrad_tile(c, accg, c.Q, 64, Th, LDP, rup(rows_b, 32) / 32);
+      }
       tr(c, 34);
-      lds_barrier();                              // all reads of the old Wo are done
+      lds_barrier();                              // the slab is free again; old Wo fully read
       tr(c, 35);
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
@@ -1225,20 +1317,20 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       relaunder(c);
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
-      // Q <- input activation of decoder layer d
+      // dgrad from the layer's weight tile staged in Q, then Q <- input activation of decoder layer d
+      f32x4 acc[2][RT];
+      zero_acc(acc);
+      dgrad_staged(c, acc, c.P, prm + md.dec_w[d], Nout, Kin);
+      tr(c, 34);
+      lds_barrier();                              // weight tile fully read
+      tr(c, 35);
+      prof(c, PH_DEC_DGRAD);
       tr(c, 31);
       load_act(c, c.Q, d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ROWS * PW, wpad(Kin));
       tr(c, 32);
       lds_barrier();
       tr(c, 36);
       prof(c, PH_DEC_LOAD);
-      f32x4 acc[2][RT];
-      zero_acc(acc);
-      dgrad_acc(c, acc, c.P, prm + md.dec_w[d], Nout, Kin, wpad(Nout) / 32, 0);
-      tr(c, 34);
-      lds_barrier();                              // old weights fully read
-      tr(c, 35);
-      prof(c, PH_DEC_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.dec_w[d], md.dec_b[d]);
       prof(c, PH_DEC_WGRAD);
       if (d > 0) {
@@ -1359,13 +1451,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     prof(c, PH_ENCB_DELTA);
     for (int e = L - 1; e >= 1; --e) {
       int Kin = J->H[e - 1], Nout = J->H[e];
+      zero_acc(acc);
+      dgrad_staged(c, acc, c.P, prm + md.enc_w[e], Nout, Kin);
+      lds_barrier();                              // weight tile fully read
+      prof(c, PH_ENCB_DGRAD);
       load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW, wpad(Kin));
       lds_barrier();
       prof(c, PH_ENCB_LOAD);
-      zero_acc(acc);
-      dgrad_acc(c, acc, c.P, prm + md.enc_w[e], Nout, Kin, wpad(Nout) / 32, 0);
-      lds_barrier();
-      prof(c, PH_ENCB_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.enc_w[e], md.enc_b[e]);
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
@@ -1433,7 +1525,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
     if (flags & NM_F_PROFILE) c.t_last = clock64();
-    if ((flags & 64) && (threadIdx.x & 63) == 0) c.tlast[threadIdx.x >> 6] = clock64();
+    if (flags & 64) c.tlast[threadIdx.x >> 6] = clock64();
     lds_barrier();
     relaunder(c);
     run_step<SCALAR_TR>(c, s);

@@ -1,0 +1,36 @@
+"""The compiled ISA of csrc/nmhip.hip must not contain register-spill traffic ahead of an EXEC-mask restore
+(tools/check_spill_exec.py explains the hazard: a lane-divergent branch + spills = lanes that never store).
+Cross-compiles for gfx950 on the CPU box; no GPU needed."""
+import importlib.util
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _mod():
+    spec = importlib.util.spec_from_file_location("check_spill_exec", ROOT / "tools" / "check_spill_exec.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_scanner_flags_the_known_bad_pattern():
+    bad_asm = """
+.LBB0_1:
+\ts_and_saveexec_b64 s[16:17], s[10:11]
+\ts_cbranch_execz .LBB0_3
+.LBB0_3:
+\ts_mov_b32 s95, s63
+\tscratch_store_dword off, v153, off offset:124 ; 4-byte Folded Spill
+\ts_or_b64 exec, exec, s[16:17]
+\tv_mov_b32 v0, v1
+.LBB0_4:
+\ts_or_b64 exec, exec, s[18:19]
+\tscratch_store_dword off, v1, off offset:8
+"""
+    bad = _mod().scan(bad_asm)
+    assert [b[0] for b in bad] == [".LBB0_3"]
+
+
+def test_kernel_isa_has_no_spill_ahead_of_exec_restore():
+    assert _mod().main() == 0

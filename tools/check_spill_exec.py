@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Build-time guard against a code-generation hazard seen with this toolchain (ROCm 7.2 clang, gfx950): when a
+lane-divergent branch sits in a region with register spills, the spill stores of values that are live in ALL
+lanes can be placed at the head of the branch's merge block, before `s_or_b64 exec, exec, ...` restores the
+execution mask -- lanes outside the branch then never store, and the later reload returns stale scratch.  (It
+showed up as an NLL off by exactly 0.5*|logvar_out| per row for one ROI column of one test shape.)
+
+The script compiles csrc/nmhip.hip to ISA and reports every basic block that touches scratch before its first
+EXEC restore.  Exit status 1 if any is found.  Fix at the source: keep divergent branches out of high-pressure
+regions (hoist descriptor loads out of per-lane selects, use selects / predicated stores instead of `if`)."""
+import re, subprocess, sys, tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def scan(asm_text: str):
+    bad, cur_label, cur = [], None, []
+
+    def check(label, insts):
+        for k, (ln, t) in enumerate(insts):
+            if re.match(r"\s*s_or_b64 exec, exec,", t):
+                sc = [(l, x.strip()) for l, x in insts[:k] if "scratch_" in x]
+                if sc:
+                    bad.append((label, ln, sc))
+                return
+            if re.match(r"\s*(s_and_saveexec|s_cbranch|s_branch|s_barrier)", t):
+                return
+
+    for i, l in enumerate(asm_text.split("\n")):
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            if cur_label is not None:
+                check(cur_label, cur)
+            cur_label, cur = l.split(":")[0], []
+        elif re.match(r"^[A-Za-z_][\w.$]*:", l):           # function label: new scope
+            if cur_label is not None:
+                check(cur_label, cur)
+            cur_label, cur = l.split(":")[0], []
+        elif l.strip() and not l.strip().startswith(";"):
+            cur.append((i + 1, l))
+    if cur_label is not None:
+        check(cur_label, cur)
+    return bad
+
+
+def main():
+    src = ROOT / "multi_modal_normative_modeling_amd" / "csrc" / "nmhip.hip"
+    with tempfile.TemporaryDirectory() as d:
+        out = Path(d) / "nmhip.s"
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+               f"-I{ROOT / 'include'}", str(src), "-o", str(out)]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        bad = scan(out.read_text())
+    print(f"blocks with scratch traffic ahead of the EXEC restore: {len(bad)}")
+    for label, ln, sc in bad:
+        print(" ", label, "line", ln, sc[:4])
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
