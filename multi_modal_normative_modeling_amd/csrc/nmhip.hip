@@ -989,9 +989,15 @@ __device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, co
   return G;
 }
 __device__ __forceinline__ float pick(const float (&a)[NM_MAX_EXP], int m) {
+  // a select chain, kept opaque: left alone the compiler turns it back into a[m], i.e. a private array in
+  // scratch memory (12 floats stored and one reloaded per element of the fusion backward loop)
   float r = a[0];
 #pragma unroll
-  for (int q = 1; q < NM_MAX_EXP; ++q) r = (q == m) ? a[q] : r;
+  for (int q = 1; q < NM_MAX_EXP; ++q) {
+    float t = (q == m) ? a[q] : r;
+    asm volatile("" : "+v"(t));
+    r = t;
+  }
   return r;
 }
 
