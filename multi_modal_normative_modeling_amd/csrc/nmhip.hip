@@ -812,8 +812,10 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
       pv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; mv[j] = pv[j]; vv[j] = pv[j];
       if (do_adam && mine[j]) {
         pv[j] = *(const GAS f32x4*)(asg(J->params) + pidx[j]);
-        mv[j] = *(const GAS f32x4*)(asg(J->adam_m) + pidx[j]);
-        vv[j] = *(const GAS f32x4*)(asg(J->adam_v) + pidx[j]);
+        // the moments are touched once per step: streaming (nt) accesses keep them from evicting the weights
+        // and activations that are re-read within the step (measured: -9 % config A, -2.5 % 3-modality)
+        mv[j] = __builtin_nontemporal_load((const GAS f32x4*)(asg(J->adam_m) + pidx[j]));
+        vv[j] = __builtin_nontemporal_load((const GAS f32x4*)(asg(J->adam_v) + pidx[j]));
       }
     }
     // bias element of this thread (first nr threads): its p/m/v fly with the slab's groups
@@ -882,8 +884,8 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
 #pragma unroll
           for (int i = 0; i < 4; ++i) { float pp = p4[i], mm = m4[i], v2 = v4[i]; adam1(ak, g[i], pp, mm, v2); p4[i] = pp; m4[i] = mm; v4[i] = v2; }
           *(GAS f32x4*)(asg(J->params) + pidx[j]) = p4;
-          *(GAS f32x4*)(asg(J->adam_m) + pidx[j]) = m4;
-          *(GAS f32x4*)(asg(J->adam_v) + pidx[j]) = v4;
+          __builtin_nontemporal_store(m4, (GAS f32x4*)(asg(J->adam_m) + pidx[j]));
+          __builtin_nontemporal_store(v4, (GAS f32x4*)(asg(J->adam_v) + pidx[j]));
         }
       }
     }
@@ -1244,8 +1246,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
                   rs += sq[i];
                 }
                 const int64_t gi = (int64_t)(c.row0 + r) * xp + dg0;
-                if (md.out_loc) *(GAS f32x4*)(asg(md.out_loc) + gi) = lo;
-                if (md.out_sqerr) *(GAS f32x4*)(asg(md.out_sqerr) + gi) = sq;
+                if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
+                if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
                 if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
               }
             }
