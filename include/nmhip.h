@@ -211,6 +211,12 @@ int nm_posthoc_metrics(const float* scores, const int32_t* labels, const int32_t
 int nm_confusion_metrics(const int32_t* pred, const int32_t* labels, const int32_t* offsets, int n_sets, double* out,
                          void* stream);
 
+/* Names SURVEY.md 8(b) lists for the boundary; same entry points under the survey's names:
+ * nm_train_steps_persistent = nm_train_steps (whole training run inside one persistent launch),
+ * nm_deviation = nm_forward (forward-only tiles with the (x - x_hat)^2 / row-mean exports). */
+int nm_train_steps_persistent(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream);
+int nm_deviation(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream);
+
 /* Stand-alone flat Adam (used by the eager API path).  t is the 1-based step count. */
 int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
                  float lr, float beta1, float beta2, float eps, int64_t t, void* stream);

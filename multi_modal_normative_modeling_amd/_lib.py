@@ -109,6 +109,8 @@ def load():
     for name in ("nm_launch", "nm_launch_scalar_tr"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
+    lib.nm_train_steps_persistent.argtypes = [vp, i32, i32, i32, vp]
+    lib.nm_deviation.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_grads.argtypes = [vp, i32, i32, vp]
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, i32, vp]
@@ -132,7 +134,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_posthoc_metrics", "nm_confusion_metrics",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
 ]
 
 

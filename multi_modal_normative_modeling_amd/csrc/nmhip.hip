@@ -2457,6 +2457,14 @@ int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, voi
   return nm_launch(jobs_dev, n_jobs, tile0, 1, n_tiles, NM_F_EXPORT, stream);
 }
 
+int nm_train_steps_persistent(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream) {
+  return nm_train_steps(jobs_dev, n_jobs, step0, n_steps, stream);
+}
+
+int nm_deviation(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream) {
+  return nm_forward(jobs_dev, n_jobs, tile0, n_tiles, stream);
+}
+
 int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, int64_t t, void* stream) {
   if (!params || !grads || !m || !v) return -1;
