@@ -26,7 +26,7 @@ def onehot(g, B, c_dim=29):
     return c
 
 
-def run_case(dims, Z, combine, B, seed, hidden=(110, 110), c_dim=29, non_linear=True):
+def run_case(dims, Z, combine, B, seed, hidden=(110, 110), c_dim=29, non_linear=True, ll32_tol=1e-4):
     g = torch.Generator().manual_seed(seed)
     spec = nm.ModelSpec(list(dims), list(hidden), Z, c_dim, non_linear)
     lay = nm.ParamLayout(spec)
@@ -53,10 +53,10 @@ def run_case(dims, Z, combine, B, seed, hidden=(110, 110), c_dim=29, non_linear=
             R.set_operand_rounding("fp32")
     row = job.loss_log[0].cpu()
     ll32, ll16 = float(res["fp32"][1]["ll"]), float(res["bf16"][1]["ll"])
-    assert abs(float(row[2]) - ll32) <= 1e-4 * abs(ll32), (float(row[2]), ll32)          # north-star bound
+    assert abs(float(row[2]) - ll32) <= ll32_tol * abs(ll32), (float(row[2]), ll32)      # north-star bound (1e-4 at batch 256)
     assert abs(float(row[2]) - ll16) <= 5e-6 * abs(ll16)
     tot32 = float(res["fp32"][1]["total"])
-    assert abs(float(row[0]) - tot32) <= 1e-4 * abs(tot32)
+    assert abs(float(row[0]) - tot32) <= ll32_tol * abs(tot32)
     mu16 = res["bf16"][0]["mu"].detach()
     assert float((job.out_mu[:B].cpu() - mu16).abs().max()) <= 3e-3 * float(mu16.abs().max())
     for m in range(len(dims)):
