@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ / TA counter passes over the bench command (one rocprofv3 --pmc pass per group, kernel-trace only).
+# usage: tools/run_pmc_sq.sh <tag>
+set -e
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcsq_$TAG
+mkdir -p $OUT
+G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"
+G2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"
+G3="TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"
+i=0
+for G in "$G1" "$G2" "$G3"; do
+  i=$((i+1))
+  rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --steps 32 --warmup 0 > $OUT/g$i.log 2>&1 || true
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "nm_step_kernel" in row.get("Kernel_Name", ""):
+            k = row["Counter_Name"]
+            agg[k][0] += 1
+            agg[k][1] += float(row["Counter_Value"])
+for k, (n, v) in sorted(agg.items()):
+    print(f"{k:34s} dispatches {n:3d}  sum {v:.6g}  per-dispatch {v / max(n, 1):.6g}")
+PY
