@@ -1553,6 +1553,33 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   }
 }
 
+// A [NR][128] block of a weight matrix with row pitch Kp (rows row0.., columns col0.. of the chunk walk): 32
+// 16-byte pieces per row = 512 contiguous bytes per row; bf16 [NR][ld] in LDS, zeros past the matrix (rows >= N,
+// columns >= Kp).  NR = 128 (8 pieces per thread) or 64 (4).
+template <int NR>
+struct WBlk { f32x4 v[(NR * 128 / 4) / WG]; };
+template <int NR>
+__device__ __forceinline__ void wblk_load(const Ctx& c, WBlk<NR>& s, gcf32 W, int N, int Kp, int row0, int col0) {
+#pragma unroll
+  for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
+    const int p = c.tid + j * WG, row = row0 + (p >> 5), col = col0 + (p & 31) * 4;
+    s.v[j] = *(const GAS f32x4*)(W + (int64_t)min(row, N - 1) * Kp + min(col, Kp - 4));
+  }
+}
+template <int NR>
+__device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf16* dst, int ld, int N, int Kp, int row0,
+                                           int col0) {
+#pragma unroll
+  for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
+    const int p = c.tid + j * WG, lr = p >> 5, lc = (p & 31) * 4;
+    const bool ok = row0 + lr < N && col0 + lc < Kp;
+    bf16x4 pk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(ok ? s.v[j][i] : 0.f);
+    *reinterpret_cast<bf16x4*>(dst + lr * ld + lc) = pk;
+  }
+}
+
 // ---- regression head (cVAE.py:2249-2253 regressor, 2318-2321 forward, 2330-2346 loss) ----------------
 // fi_pred = W3 relu(W2 relu(W1 cat_m(x_m - x_hat_m) + b1) + b2) + b3;  loss = mean_r (fi_pred - FI)^2.
 // One workgroup per (job, 256-row tile); same operand conventions as the trunk: bf16 MFMA operands,
@@ -1655,19 +1682,25 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   (void)wl;
   const int nch = (SD + PW - 1) / PW;
 
-  // ---- layer 1: h1 = relu(W1 resid + b1), the residual streamed through Q ----
+  // ---- layer 1: h1 = relu(W1 resid + b1): the residual streamed through Q, the matching 128-column block of
+  // W1 through P (free until h1 exists), both as coalesced copies; next block's weights fly during the MFMAs ----
   f32x4 acc[2][RT];
   bias_acc(c, acc, b1, N1, 0);
+  const int Kp1 = kpitch(SD);
+  WBlk<128> wb;
+  wblk_load<128>(c, wb, W1, N1, Kp1, 0, 0);
   for (int ch = 0; ch < nch; ++ch) {
     relaunder(c);
     const int k0 = ch * PW, valid = min(PW, SD - k0), ksteps = rup(valid, 32) / 32;
     resid_chunk_to_Q(c, M, SD, k0);
+    wblk_store<128>(c, wb, c.P, LDP, N1, Kp1, 0, k0);
     lds_barrier();
+    if (ch + 1 < nch) wblk_load<128>(c, wb, W1, N1, Kp1, 0, k0 + PW);
     if (bwd) store_act(c, ws_res + (int64_t)ch * ROWS * PW, c.Q, PW);
     for (int ks = 0; ks < ksteps; ++ks) {
       bf16x8 wf[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wf[t] = w_frag(W1, N1, SD, (c.wn + 4 * t) * 16 + c.c16, k0 + ks * 32 + 8 * c.g);
+      for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.P, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         bf16x8 a = lds_frag(c.Q, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
@@ -1769,20 +1802,20 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   for (int ch = 0; ch < nch; ++ch) {
     relaunder(c);
     const int k0 = ch * PW, valid = min(PW, SD - k0);
+    // the W1 block of this chunk comes as two 64-row half tiles through the gradient slab (transposing reads)
+    __bf16* Th = reinterpret_cast<__bf16*>(c.stage);
+    WBlk<64> ha, hb;
+    wblk_load<64>(c, ha, W1, N1, Kp1, 0, k0);
+    wblk_load<64>(c, hb, W1, N1, Kp1, 64, k0);
     load_act(c, c.Q, ws_res + (int64_t)ch * ROWS * PW, PW);
+    wblk_store<64>(c, ha, Th, LDP, N1, Kp1, 0, k0);
     lds_barrier();
     zero_acc(acc);
-    for (int s = 0; s < N1 / 32; ++s) {
-      bf16x8 wf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) wf[t] = w_frag_t(W1, N1, SD, s * 32 + 8 * c.g, k0 + (c.wn + 4 * t) * 16 + c.c16);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, s * 32 + 8 * c.g);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
-      }
-    }
+    dgrad_tile(c, acc, c.P, 0, Th, LDP, 2);
+    lds_barrier();
+    wblk_store<64>(c, hb, Th, LDP, N1, Kp1, 64, k0);
+    lds_barrier();
+    dgrad_tile(c, acc, c.P, 64, Th, LDP, 2);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
