@@ -290,7 +290,9 @@ __device__ __forceinline__ float randn_ctr(uint64_t seed, uint32_t step, uint32_
   uint64_t h2 = splitmix64(h);
   float u1 = ((uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1]
   float u2 = (uint32_t)(h2 >> 40) * (1.0f / 16777216.0f);           // [0, 1)
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+  // hardware transcendentals (v_log_f32 = log2, v_cos_f32 takes revolutions): the draw is a random number, not
+  // a parity quantity -- parity runs inject eps
+  return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 
 // ---- Adam (torch.optim.Adam as configured at cVAE.py:1111-1116) -------------------------------

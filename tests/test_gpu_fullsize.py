@@ -229,3 +229,35 @@ def test_regression_model_full_size_with_head():
     assert abs(float(losses["ll"]) - ll32) <= 1e-4 * abs(ll32)                                              # north-star bound
     assert abs(float(losses["regression"]) - float(ref["bf16"][1]["regression"])) <= 5e-3 * float(ref["bf16"][1]["regression"])
     _grad_check(got, ref["bf16"][2])
+
+
+def test_in_kernel_normal_draw_statistics():
+    """The counter-based generator used when no eps is injected (torch.randn_like in the reference, cVAE.py:1132):
+    recover eps = (z - mu) / exp(logvar / 2) from the exports of a forward pass over 4 tiles and check that it is
+    standard normal (moments, tails, no correlation between neighbouring latent columns), reproducible for a
+    fixed (seed, step) and different across seeds."""
+    g = torch.Generator().manual_seed(8)
+    N, D, Z = 1024, 64, 64
+    spec = nm.ModelSpec([D], [32], Z, 3)
+    P = nm.ParamLayout(spec).init_reference_rule(2)
+    x = torch.randn(N, D, generator=g)
+    c = onehot(g, N, 3)
+
+    def draws(seed):
+        t = nm.Table(x, c, DEV)
+        job = nm.Job(spec, [t], combine="poe", state=P, seed=seed, n_tiles_ws=t.n_tiles)
+        job.enable_exports(loc=False, sqerr=False, rowdev=False, latent=True)
+        nm.JobSet([job]).forward()
+        torch.cuda.synchronize()
+        return ((job.out_z[:N] - job.out_mu[:N]) / torch.exp(0.5 * job.out_logvar[:N])).cpu().double()
+
+    e = draws(7)
+    assert torch.isfinite(e).all()
+    n = e.numel()
+    assert abs(float(e.mean())) < 4.0 / math.sqrt(n)
+    assert abs(float(e.var()) - 1.0) < 0.02
+    assert abs(float((e ** 3).mean())) < 0.03 and abs(float((e ** 4).mean()) - 3.0) < 0.1
+    assert 0.25 < float((e.abs() > 1.0).double().mean()) < 0.39 and float(e.abs().max()) < 6.5
+    assert abs(float((e[:, :-1] * e[:, 1:]).mean())) < 0.01 and abs(float((e[:-1] * e[1:]).mean())) < 0.01
+    assert torch.equal(e, draws(7))
+    assert float((e - draws(8)).abs().mean()) > 0.5
