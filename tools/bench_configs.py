@@ -87,3 +87,30 @@ js = nm.JobSet(jobs)
 us = timed(js.train_endtoend, a.steps)
 n_par = jobs[0].layout.n_params
 report("config 5 end-to-end Z=64 cls[128,64,32]", us, 4.0 * 256 * (1137 + 29 + 64) + 24.0 * n_par, a.jobs)
+
+# deviation pass (..._regression.py:163-192): forward-only, one workgroup per (model, 256-row tile), squared residuals out
+del js, jobs
+tabs.clear()
+torch.cuda.empty_cache()
+N = 1064
+xall = prep.robust_scaler_transform(cohort.x["T1w_sMRI"][:N].astype(np.float32), *prep.robust_scaler_fit(cohort.x["T1w_sMRI"][:N].astype(np.float32))).astype(np.float32)
+call = prep.one_hot_covariates(cohort.age[:N], cohort.gender[:N])
+tab = nm.Table(xall, call, DEV)
+djobs = []
+for j in range(a.jobs):
+    spec = nm.ModelSpec([379], [110, 110], 10, 29)
+    job = nm.Job(spec, [tab], combine="poe", seed=j, init_seed=42 + j, n_tiles_ws=tab.n_tiles)
+    job.enable_exports(loc=False, sqerr=True, rowdev=True, latent=False)
+    djobs.append(job)
+djs = nm.JobSet(djobs)
+djs.forward(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(8):
+    djs.forward()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 8
+rows = N * a.jobs
+byt = rows * 379 * 8.0                                   # 4 N D read + 4 N D write
+print(f"{'deviation pass 379 ROI, N=1064 x %d models' % a.jobs:44s} {ms * 1e3:8.1f} us/pass  {rows / ms * 1e3:12.0f} rows/s  "
+      f"{byt / ms / 1e6:8.1f} GB/s algorithmic  frac {byt / ms / 1e6 / 8000:5.3f}", flush=True)
