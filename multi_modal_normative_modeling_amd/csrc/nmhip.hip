@@ -370,70 +370,33 @@ __device__ __forceinline__ void xchunk_store(const Ctx& c, const XStage& s, __bf
 
 // ---- LDS-staged weight tiles ---------------------------------------------------------------------
 // A block of up to 128 weight rows is contiguous in the flat buffer (row pitch = kpitch(K)), so the workgroup
-// copies it with perfectly coalesced 16-byte loads (piece p = thread + j * WG <-> floats [4p, 4p+4)), converts
-// to bf16 and lays it out [128][ld] in LDS; the MFMA A-fragments are then ds_read_b128 like the activations.
-// Rows >= nrows and the columns [Kp, wcols) are written as zeros (finite operands for the padded lanes).
-constexpr int WPIECES = (128 * 128 / 4) / WG;      // 16-byte pieces per thread for a full 128 x 128 block
-struct WStage { f32x4 v[WPIECES]; };
-__device__ __forceinline__ void wstage_load(const Ctx& c, WStage& s, gcf32 W, int npieces) {
+// copies it with coalesced 16-byte loads, converts to bf16 and lays it out [rows][ld] in LDS; the MFMA
+// A-fragments are then ds_read_b128 like the activations (dgrad: the transposing read).  Thread -> (row, piece)
+// is a shift and a mask (32 pieces of 4 floats per row; lanes past the row end idle), no division.
+// A [NR][128] block of a weight matrix with row pitch Kp (rows row0.., columns col0.. of the chunk walk): 32
+// 16-byte pieces per row = 512 contiguous bytes per row; bf16 [NR][ld] in LDS, zeros past the matrix (rows >= N,
+// columns >= Kp).  NR = 128 (8 pieces per thread) or 64 (4).
+template <int NR>
+struct WBlk { f32x4 v[(NR * 128 / 4) / WG]; };
+template <int NR>
+__device__ __forceinline__ void wblk_load(const Ctx& c, WBlk<NR>& s, gcf32 W, int N, int Kp, int row0, int col0) {
 #pragma unroll
-  for (int j = 0; j < WPIECES; ++j) s.v[j] = *(const GAS f32x4*)(W + 4 * min(c.tid + j * WG, npieces - 1));
-}
-__device__ __forceinline__ void wstage_store(const Ctx& c, const WStage& s, __bf16* dst, int ld, int Kp, int wcols,
-                                             int npieces) {
-  const int kp4 = Kp >> 2;
-  const float rk = 1.0f / (float)kp4;
-#pragma unroll
-  for (int j = 0; j < WPIECES; ++j) {
-    const int p = c.tid + j * WG;
-    const int row = idiv(p, kp4, rk), col = (p - row * kp4) * 4;
-    if (row < 128) {
-      bf16x4 pk;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(p < npieces ? s.v[j][i] : 0.f);
-      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = pk;
-    }
-  }
-  const int padc = wcols - Kp;                      // 0 .. 32, a multiple of 8
-  if (padc > 0) {
-    const int pp = padc >> 2;
-    const float rp = 1.0f / (float)pp;
-    for (int e = c.tid; e < 128 * pp; e += WG) {
-      const int row = idiv(e, pp, rp), col = Kp + (e - row * pp) * 4;
-      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-    }
+  for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
+    const int p = c.tid + j * WG, row = row0 + (p >> 5), col = col0 + (p & 31) * 4;
+    s.v[j] = *(const GAS f32x4*)(W + (int64_t)min(row, N - 1) * Kp + min(col, Kp - 4));
   }
 }
-
-// Half tile: up to 64 weight rows into a [64][ld] bf16 tile (the 17 KB gradient slab doubles as its home).
-constexpr int HPIECES = (64 * 128 / 4) / WG;
-struct WHalf { f32x4 v[HPIECES]; };
-__device__ __forceinline__ void whalf_load(const Ctx& c, WHalf& s, gcf32 W, int npieces) {
+template <int NR>
+__device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf16* dst, int ld, int N, int Kp, int row0,
+                                           int col0) {
 #pragma unroll
-  for (int j = 0; j < HPIECES; ++j) s.v[j] = *(const GAS f32x4*)(W + 4 * min(c.tid + j * WG, max(npieces, 1) - 1));
-}
-__device__ __forceinline__ void whalf_store(const Ctx& c, const WHalf& s, __bf16* dst, int ld, int Kp, int wcols, int npieces) {
-  const int kp4 = Kp >> 2;
-  const float rk = 1.0f / (float)kp4;
+  for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
+    const int p = c.tid + j * WG, lr = p >> 5, lc = (p & 31) * 4;
+    const bool ok = row0 + lr < N && col0 + lc < Kp;
+    bf16x4 pk;
 #pragma unroll
-  for (int j = 0; j < HPIECES; ++j) {
-    const int p = c.tid + j * WG;
-    const int row = idiv(p, kp4, rk), col = (p - row * kp4) * 4;
-    if (row < 64) {
-      bf16x4 pk;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(p < npieces ? s.v[j][i] : 0.f);
-      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = pk;
-    }
-  }
-  const int padc = wcols - Kp;
-  if (padc > 0) {
-    const int pp = padc >> 2;
-    const float rp = 1.0f / (float)pp;
-    for (int e = c.tid; e < 64 * pp; e += WG) {
-      const int row = idiv(e, pp, rp), col = Kp + (e - row * pp) * 4;
-      *reinterpret_cast<bf16x4*>(dst + row * ld + col) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-    }
+    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(ok ? s.v[j][i] : 0.f);
+    *reinterpret_cast<bf16x4*>(dst + lr * ld + lc) = pk;
   }
 }
 
@@ -533,14 +496,14 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
   relaunder(c);
   const int ksteps = wpad(K) / 32;       // <= 4
   const int ntn = wpad(N) / 16;
-  const int Kp = kpitch(K), npieces = N * (Kp >> 2);
+  const int Kp = kpitch(K);
   // the layer's weights: coalesced global -> registers -> bf16 tile in Q (free during the forward chain)
-  WStage wsg;
-  wstage_load(c, wsg, W, npieces);
+  WBlk<128> wsg;
+  wblk_load<128>(c, wsg, W, N, Kp, 0, 0);
   tr(c, 0);
   f32x4 acc[2][RT];
   bias_acc(c, acc, b, N, 0);
-  wstage_store(c, wsg, c.Q, LDP, Kp, wpad(K), npieces);
+  wblk_store<128>(c, wsg, c.Q, LDP, N, Kp, 0, 0);
   lds_barrier();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -722,11 +685,11 @@ __device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], co
 __device__ __forceinline__ void dgrad_staged(const Ctx& cc, f32x4 (&acc)[2][RT], const __bf16* A, gcf32 W, int N, int K) {
   Ctx c = cc;
   relaunder(c);
-  const int Kp = kpitch(K), npieces = N * (Kp >> 2);
-  WStage wsg;
-  wstage_load(c, wsg, W, npieces);
+  const int Kp = kpitch(K);
+  WBlk<128> wsg;
+  wblk_load<128>(c, wsg, W, N, Kp, 0, 0);
   tr(c, 33);
-  wstage_store(c, wsg, c.Q, LDP, Kp, wpad(K), npieces);
+  wblk_store<128>(c, wsg, c.Q, LDP, N, Kp, 0, 0);
   lds_barrier();
   dgrad_tile(c, acc, A, 0, c.Q, LDP, wpad(N) / 32);
 }
@@ -1148,9 +1111,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         // everything this chunk reads from memory is requested first: the chunk's weight rows (contiguous:
         // coalesced copy into a bf16 tile in Q, free until the epilogue), the fp32 inputs of the residual
         // (rows are always inside the zero-padded table) and logvar_out
-        const int Kpo = kpitch(Hl), wpieces = valid * (Kpo >> 2);
-        WStage wsg;
-        wstage_load(c, wsg, Wo + (int64_t)d0 * Kpo, wpieces);
+        const int Kpo = kpitch(Hl);
+        WBlk<128> wsg;
+        wblk_load<128>(c, wsg, Wo + (int64_t)d0 * Kpo, valid, Kpo, 0, 0);
         f32x4 xin[RT];                     // inputs of feature tile t = 0 now, t = 1 after tile 0's epilogue
         float sv[2][4];
 #pragma unroll
@@ -1169,7 +1132,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         tr(c, 18);
         f32x4 acc[2][RT];
         bias_acc(c, acc, bo, D, d0);
-        wstage_store(c, wsg, c.Q, LDP, Kpo, wpad(Hl), wpieces);
+        wblk_store<128>(c, wsg, c.Q, LDP, valid, Kpo, 0, 0);
         lds_barrier();
         tr(c, 17);
 #pragma unroll
@@ -1285,12 +1248,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       // gradient slab, read with the transposing LDS load; both halves are requested now.
       relaunder(c);
       __bf16* Th = reinterpret_cast<__bf16*>(c.stage);
-      const int Kph = kpitch(Hl), kp4h = Kph >> 2;
+      const int Kph = kpitch(Hl);
       const int rows_a = min(valid, 64), rows_b = valid - rows_a;
-      WHalf ha, hb;
-      whalf_load(c, ha, Wo + (int64_t)d0 * Kph, rows_a * kp4h);
-      whalf_load(c, hb, Wo + (int64_t)(d0 + (rows_b > 0 ? 64 : 0)) * Kph, rows_b * kp4h);   // never past the tensor
-      whalf_store(c, ha, Th, LDP, Kph, wpad(Hl), rows_a * kp4h);
+      WBlk<64> ha, hb;
+      wblk_load<64>(c, ha, Wo + (int64_t)d0 * Kph, valid, Kph, 0, 0);
+      wblk_load<64>(c, hb, Wo + (int64_t)d0 * Kph, valid, Kph, 64, 0);      // rows clamp to the chunk's last row
+      wblk_store<64>(c, ha, Th, LDP, valid, Kph, 0, 0);
       lds_barrier();                              // delta chunk in Q and half tile A complete
       tr(c, 21);
       prof(c, PH_OUT_GEMM);
@@ -1300,7 +1263,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       dgrad_tile(c, accg, c.Q, 0, Th, LDP, rup(rows_a, 32) / 32);
       if (rows_b > 0) {
         lds_barrier();                            // half A fully read
-        whalf_store(c, hb, Th, LDP, Kph, wpad(Hl), rows_b * kp4h);
+        wblk_store<64>(c, hb, Th, LDP, valid, Kph, 64, 0);
         lds_barrier();
         dgrad_tile(c, accg, c.Q, 64, Th, LDP, rup(rows_b, 32) / 32);
       }
@@ -1552,33 +1515,6 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     tr(c, 62);
     __syncthreads();
     tr(c, 63);
-  }
-}
-
-// A [NR][128] block of a weight matrix with row pitch Kp (rows row0.., columns col0.. of the chunk walk): 32
-// 16-byte pieces per row = 512 contiguous bytes per row; bf16 [NR][ld] in LDS, zeros past the matrix (rows >= N,
-// columns >= Kp).  NR = 128 (8 pieces per thread) or 64 (4).
-template <int NR>
-struct WBlk { f32x4 v[(NR * 128 / 4) / WG]; };
-template <int NR>
-__device__ __forceinline__ void wblk_load(const Ctx& c, WBlk<NR>& s, gcf32 W, int N, int Kp, int row0, int col0) {
-#pragma unroll
-  for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
-    const int p = c.tid + j * WG, row = row0 + (p >> 5), col = col0 + (p & 31) * 4;
-    s.v[j] = *(const GAS f32x4*)(W + (int64_t)min(row, N - 1) * Kp + min(col, Kp - 4));
-  }
-}
-template <int NR>
-__device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf16* dst, int ld, int N, int Kp, int row0,
-                                           int col0) {
-#pragma unroll
-  for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
-    const int p = c.tid + j * WG, lr = p >> 5, lc = (p & 31) * 4;
-    const bool ok = row0 + lr < N && col0 + lc < Kp;
-    bf16x4 pk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(ok ? s.v[j][i] : 0.f);
-    *reinterpret_cast<bf16x4*>(dst + lr * ld + lc) = pk;
   }
 }
 
