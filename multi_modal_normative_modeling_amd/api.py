@@ -18,7 +18,7 @@ All arithmetic runs in libnmhip.so; there is no CPU fallback (NmError without a 
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

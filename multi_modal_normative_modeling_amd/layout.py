@@ -9,7 +9,7 @@ Inside the flat buffer every tensor starts on a 16-byte boundary and every weigh
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
 
 import torch

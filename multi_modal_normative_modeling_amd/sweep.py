@@ -9,7 +9,6 @@ CPU tests) -- there is no data-path exchange.
 """
 from __future__ import annotations
 
-import math
 import time
 from dataclasses import dataclass
 from pathlib import Path

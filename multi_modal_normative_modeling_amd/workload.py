@@ -6,9 +6,8 @@ same plus the early-fusion table as a fourth expert.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
-import numpy as np
 
 from . import prep
 from .engine import Job, Table
