@@ -587,8 +587,53 @@ class cVAE_multimodal_endtoend(_HeadBase):
                 "mu": j.out_mu[:B].clone(), "logvar": j.out_logvar[:B].clone(),
                 "logits": j.out_logits[:B, : self.num_classes].clone()}
 
+    def _unimodal(self, m: int, bank: str) -> "cVAE_multimodal":
+        """One-modality view (encoder m + decoder m of one bank) for the stand-alone encode / decode calls."""
+        self._dev()
+        cache = self.__dict__.setdefault("_uni", {})
+        if (m, bank) not in cache:
+            u = cVAE_multimodal([self.input_dim_list[m]], self.spec.hidden, self.latent_dim, self.c_dim,
+                                self.learning_rate, 1, self.spec.non_linear)
+            u.to(self._device)
+            cache[(m, bank)] = u
+        u = cache[(m, bank)]
+        sd = _Base.state_dict(self)
+        st = {}
+        for k in u.layout.names:
+            if k.startswith("encoder_list.0."):
+                st[k] = sd[k.replace("encoder_list.0.", f"encoder_list.{m}.")]
+            elif k.startswith("decoder_list.0."):
+                st[k] = sd[k.replace("decoder_list.0.", f"decoder_list_{bank}.{m}.")]
+            else:
+                st[k] = torch.zeros(u.layout.shapes[k])          # alpha of the one-expert view: unused (bypass)
+        u.load_state_dict(st)
+        return u
+
+    def encode(self, xes, cs):
+        """cVAE.py:2064-2076: every modality's own (mu, logvar), stacked [M, B, Z]."""
+        mus, lvs = [], []
+        for m in range(self.modalities):
+            mu, lv = self._unimodal(m, "health").encode(xes[m], cs[m], 0)
+            mus.append(mu); lvs.append(lv)
+        return torch.stack(mus), torch.stack(lvs)
+
+    def combine_latent(self, mus, logvars):
+        """cVAE.py:2083-2090 (product of experts, no single-expert bypass)."""
+        T = 1 / torch.exp(logvars)
+        return torch.sum(mus * T, dim=0) / torch.sum(T, dim=0), torch.log(1 / torch.sum(T, dim=0))
+
+    def decode(self, z, cs, group):
+        """cVAE.py:2092-2104: every modality's reconstruction from one decoder bank."""
+        if group not in ("health", "disease"):
+            raise ValueError("group must be 'health' or 'disease'")
+        return [NormalLike(self._unimodal(m, group).decode(z, cs[m], 0).loc, self._scale_bank(m, group))
+                for m in range(self.modalities)]
+
     def calc_kl(self, mu, logvar):
         return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1).mean()
+
+    def calc_recon_loss(self, x, x_recon):
+        return -x_recon.log_prob(x.to(x_recon.loc.device)).sum(dim=1).mean()              # cVAE.py:2128-2132
 
     def compute_deviation(self, x, x_recon):
         return ((x - x_recon.mean) ** 2).mean(dim=1)                          # cVAE.py:2134-2138

@@ -249,6 +249,19 @@ def test_endtoend_model_matches_reference():
     model._eps_override = None
     logits = model.predict([x.to(DEV) for x in g.xs(0)], [g.t("c")[0].to(DEV)] * g.M)
     assert rel_err(logits.cpu(), torch.from_numpy(g.z["predict"])) < 0.1
+    # stand-alone encode / combine_latent / decode (cVAE.py:2064-2104) against the oracle on the trained weights
+    xes0, c0 = [x.to(DEV) for x in g.xs(0)], g.t("c")[0].to(DEV)
+    mus, lvs = model.encode(xes0, [c0] * g.M)
+    mu_j, lv_j = model.combine_latent(mus, lvs)
+    rs = R.Spec(g.dims, g.hidden, g.Z, g.c_dim, True, kind="endtoend", classifier_layers=layers)
+    Pt = {k: v for k, v in model.state_dict().items()}
+    bn = {k: v for k, v in Pt.items() if "running" in k}
+    of = R.forward_endtoend(Pt, rs, g.xs(0), [g.t("c")[0]] * g.M, torch.zeros(g.B, g.Z), training=False, bn_stats=bn)
+    assert mus.shape == (g.M, g.B, g.Z) and rel_err(mu_j.cpu(), of["mu"]) < 2e-2 and rel_err(lv_j.cpu(), of["logvar"]) < 2e-2
+    recs = model.decode(of["mu"].to(DEV), [c0] * g.M, "disease")          # eps = 0 in the oracle run: z = mu
+    assert rel_err(recs[1].loc.cpu(), of["locs_d"][1]) < 2e-2
+    with pytest.raises(ValueError):
+        model.decode(of["mu"].to(DEV), [c0] * g.M, "other")
 
 
 def test_fused_endtoend_training_matches_reference_trajectory():
