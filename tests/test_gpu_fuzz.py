@@ -76,3 +76,91 @@ def test_random_shape_fused_adam_steps(seed):
     worst = max(float((sd[k] - P16[k]).abs().max()) for k in P16)
     assert worst <= 2.0 * lr * n_steps + 1e-6, worst
     assert n_off <= 0.02 * n_steps * n_tot + 2, (n_off, n_tot)
+
+
+@pytest.mark.parametrize("seed", range(200, 206))
+def test_random_shape_head_models(seed):
+    """Regression and end-to-end models at random shapes (residual widths that straddle chunk and modality
+    boundaries, 0-3 classifier blocks of random width, 2-4 classes, ragged batches): losses and every gradient
+    against the oracle with the kernels' operand rounding."""
+    import multi_modal_normative_modeling_amd as nm
+    from oracle import cvae_ref as R
+    rng = np.random.default_rng(seed)
+    M = int(rng.integers(1, 4))
+    dims = [int(rng.integers(5, 300)) for _ in range(M)]
+    hidden = [int(rng.integers(8, 100)) for _ in range(int(rng.integers(1, 3)))]
+    Z = int(rng.integers(2, 33))
+    B = int(rng.choice([5, 64, 130, 256]))
+    g = torch.Generator().manual_seed(seed)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    eps = torch.randn(B, Z, generator=g)
+
+    def check(got, P, skip=()):
+        for k, v in P.items():
+            if v.grad is None or k.endswith(skip) or float(v.grad.norm()) == 0.0:
+                continue
+            a, r = got[k].flatten().float(), v.grad.flatten()
+            if a.numel() < 8:
+                assert float((a - r).norm()) <= 0.2 * float(r.norm()) + 1e-6, k
+                continue
+            cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+            assert cos > 0.98 and float((a - r).norm() / r.norm()) < 0.2, (k, cos)
+
+    # ---- regression ----
+    torch.manual_seed(seed)
+    c2 = torch.rand(B, 2, generator=g) * 3
+    fi = torch.randn(B, 1, generator=g) + 1.0
+    reg = nm.cVAE_multimodal_regression(dims, hidden, Z, 2, modalities=M, non_linear=True)
+    reg.to("cuda:0")
+    sd0 = {k: v.clone() for k, v in reg.state_dict().items()}
+    reg._eps_override = eps
+    out = reg.forward_multimodal([x.to("cuda:0") for x in xes], [c2.to("cuda:0")] * M, "gpoe")
+    lo = reg.loss_function_multimodal(xes, out, fi.to("cuda:0"), lambda_reg=0.5)
+    reg.optimizer1.zero_grad()
+    lo["total"].backward()
+    got = {n: p.grad.detach().cpu() for n, p in reg.named_parameters() if p.grad is not None}
+    spec = R.Spec(dims, hidden, Z, 2, True, kind="regression")
+    P = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        fw = R.forward_regression(P, spec, xes, [c2] * M, "gpoe", eps)
+        ol = R.loss_regression(spec, xes, fw, fi, lambda_reg=0.5)
+        ol["total"].backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    assert abs(float(lo["regression"]) - float(ol["regression"])) <= 1e-2 * float(ol["regression"]) + 1e-6
+    assert abs(float(lo["total"]) - float(ol["total"])) <= 2e-4 * abs(float(ol["total"]))
+    check(got, P)
+
+    # ---- end-to-end ----
+    n_layers = int(rng.integers(1, 4))
+    layers = [int(rng.integers(4, 129)) for _ in range(n_layers)]
+    ncls = int(rng.integers(2, 5))
+    c7 = torch.rand(B, 7, generator=g)
+    labels = torch.randint(0, ncls, (B,), generator=g)
+    torch.manual_seed(seed + 1)
+    e2e = nm.cVAE_multimodal_endtoend(dims, hidden, Z, 7, modalities=M, non_linear=True, classifier_layers=layers,
+                                      dropout_rate=0.0, num_classes=ncls)
+    e2e.to("cuda:0")
+    e2e.train()
+    sd0 = {k: v.clone() for k, v in e2e.state_dict().items()}
+    e2e._eps_override = eps
+    fwd = e2e.forward([x.to("cuda:0") for x in xes], [c7.to("cuda:0")] * M)
+    # the hinge is defined for two classes (labels 0 / 1 weight the two branches): keep it out for ncls > 2
+    wc = 0.6 if ncls == 2 else 0.0
+    le = e2e.loss_function(xes, fwd, labels.to("cuda:0"), margin=0.4, weightcontrastive=wc)
+    e2e.optimizer.zero_grad()
+    le["total_loss"].backward()
+    got = {n: p.grad.detach().cpu() for n, p in e2e.named_parameters() if p.grad is not None}
+    spec = R.Spec(dims, hidden, Z, 7, True, kind="endtoend", classifier_layers=layers)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        of = R.forward_endtoend(P, spec, xes, [c7] * M, eps, training=True)
+        oe = R.loss_endtoend(spec, xes, of, labels, margin=0.4, weightcontrastive=wc)
+        oe["total_loss"].backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    assert abs(float(le["classification_loss"]) - float(oe["classification_loss"])) <= 2e-2 * float(oe["classification_loss"]) + 1e-5
+    assert abs(float(le["total_loss"]) - float(oe["total_loss"])) <= 5e-3 * abs(float(oe["total_loss"]))
+    check(got, P, skip=tuple(f"classifier.{4 * i}.bias" for i in range(n_layers)))
