@@ -3,8 +3,8 @@ reference's own cVAE class surface).  See DESIGN.md."""
 from . import _lib
 from .layout import ModelSpec, ParamLayout
 from .engine import Table, Job, JobSet, adam_step
-from .api import cVAE, cVAE_multimodal, cVAE_multimodal_regression, cVAE_multimodal_endtoend, NormalLike
+from .api import cVAE, cVAE_multimodal, cVAE_multimodal_regression, cVAE_multimodal_endtoend, mmJSD, NormalLike
 
 __all__ = ["ModelSpec", "ParamLayout", "Table", "Job", "JobSet", "adam_step", "cVAE", "cVAE_multimodal", "cVAE_multimodal_regression",
-           "cVAE_multimodal_endtoend", "NormalLike",
+           "cVAE_multimodal_endtoend", "mmJSD", "NormalLike",
            "_lib"]

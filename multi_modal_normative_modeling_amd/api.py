@@ -188,7 +188,8 @@ class _Base(nn.Module):
         # reuse one Job (buffers) across calls; only the tables change
         if self._job is None or self._job.combine != combine.lower() or self._job.tables[0].rows_alloc != tables[0].rows_alloc:
             self._job = Job(self.spec, tables, combine=combine, state=_Base.state_dict(self), lr=self._lr,
-                            kl_weight=self._kl_weight, loss_cap=1, single_bypass=self.spec.kind != "endtoend")
+                            kl_weight=self._kl_weight, loss_cap=1,
+                            single_bypass=getattr(self, "_single_bypass", self.spec.kind != "endtoend"))
             self._job.params = self._flat.data          # share storage with the module's parameters
             self._job.enable_exports()
         j = self._job
@@ -317,6 +318,27 @@ class cVAE_multimodal(_Base):
 
     def reconstruction_deviation_multimodal(self, xes, x_preds):
         return [np.sum((xes[m] - x_preds[m]) ** 2, axis=1) / xes[m].shape[1] for m in range(self.modalities)]
+
+
+class mmJSD(cVAE_multimodal):
+    """cVAE.py:1354-1448 (baseline zoo).  Same encoders / decoders / `alpha_m_list` and the same
+    ELBO sum as cVAE_multimodal; the latent is always the plain product of experts (`combine_latent` ignores the
+    `combine` argument and has no single-expert bypass), and the JSD term of its loss compares the joint posterior
+    with itself (`multimodal_jsd([mu_multimodal] * M, ...)`, :1426), i.e. it is identically zero with zero
+    gradient.  So the step kernel runs it unchanged: PoE, bypass off; `alpha_m_list` receives no gradient."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._single_bypass = False
+
+    def forward_multimodal(self, xes, cs, combine):
+        return super().forward_multimodal(xes, cs, "poe")
+
+    def pred_recon(self, xes, c, DEVICE, combine):
+        return super().pred_recon(xes, c, DEVICE, "poe")
+
+    def reparameterize(self, mu, logvar):
+        return self.reparameterise(mu, logvar)
 
 
 class cVAE(_Base):

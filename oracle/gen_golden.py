@@ -80,11 +80,12 @@ def adam_np(opt, model, prefix):
     return out
 
 
-def case_multimodal(ref, name, dims, c_dim, hidden, Z, B, combine, n_steps, seed, int_cov=True, store_steps=(1,)):
+def case_multimodal(ref, name, dims, c_dim, hidden, Z, B, combine, n_steps, seed, int_cov=True, store_steps=(1,),
+                    cls="cVAE_multimodal"):
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
     M = len(dims)
-    model = ref.cVAE_multimodal(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
+    model = getattr(ref, cls)(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
                                 learning_rate=1e-4, modalities=M, non_linear=True)
     out = {"meta": np.array([M, c_dim, Z, B, n_steps]), "dims": np.array(dims), "hidden": np.array(hidden),
            "combine": np.array(combine)}
@@ -312,6 +313,15 @@ def case_csv_headers(name):
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     ref = _import_reference()
+    only = set(sys.argv[1:])          # optional: names of the cases to (re)generate
+    if only:
+        import builtins
+        keep = lambda fn: (lambda r, name, *a, **k: fn(r, name, *a, **k) if name in only else None)
+        g = globals()
+        for fname in ("case_multimodal", "case_single", "case_deviation", "case_regression", "case_endtoend"):
+            g[fname] = keep(g[fname])
+        orig_csv = g["case_csv_headers"]
+        g["case_csv_headers"] = lambda name: orig_csv(name) if name in only else None
     # small shapes: every combiner, ragged rows, float vs int covariates
     for comb in ("poe", "gpoe", "moe", "mopoe"):
         case_multimodal(ref, f"mm3_{comb}", (23, 17, 29), 7, (24, 16), 6, 19, comb, 3, seed=100, store_steps=(1, 3))
@@ -328,6 +338,9 @@ def main():
     case_csv_headers("csv_layouts")
     case_regression(ref, "reg3_gpoe", (23, 17, 29), 2, (24, 16), 6, 32, "gpoe", 3, seed=107)
     case_endtoend(ref, "e2e3", (23, 17, 29), 7, (24, 16), 8, 32, (16, 8), 3, seed=108)
+    # baseline zoo: mmJSD (cVAE.py:1354-1448) = product of experts without the single-expert
+    # bypass; its JSD term compares the joint posterior with itself and is identically zero
+    case_multimodal(ref, "mmjsd3", (23, 17, 29), 7, (24, 16), 6, 19, "gpoe", 3, seed=109, store_steps=(3,), cls="mmJSD")
 
 
 if __name__ == "__main__":

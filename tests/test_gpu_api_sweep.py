@@ -507,3 +507,31 @@ def test_endtoend_sweep_small():
         assert np.isfinite([r["accuracy"], r["sensitivity"], r["specificity"], r["f1_score"], r["final_ce"]]).all()
         assert r["final_ce"] < 0.5 * r0["final_ce"], (r0["final_ce"], r["final_ce"])
         assert r["accuracy"] > 0.8 and r["n_pos"] + r["n_neg"] == 64
+
+
+def test_mmjsd_matches_reference():
+    """mmJSD of the baseline zoo (cVAE.py:1354-1448) on the step kernel: losses, latent and the 3-step Adam
+    trajectory of the reference class itself (golden mmjsd3); `combine` is ignored as there."""
+    g = Golden("mmjsd3")
+    model = nm.mmJSD(g.dims, g.hidden, g.Z, g.c_dim, learning_rate=1e-4, modalities=g.M, non_linear=True)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    for s in range(g.n_steps):
+        xes = [x.to(DEV) for x in g.xs(s)]
+        c = g.t("c")[s].long().to(DEV)
+        model._eps_override = g.t("eps")[s]
+        fwd = model.forward_multimodal(xes, [c] * g.M, "gpoe")
+        loss = model.loss_function_multimodal(xes, fwd)
+        ref = g.z[f"loss{s}"]
+        assert abs(float(loss["ll"]) - ref[2]) <= 1e-4 * abs(ref[2]), s
+        assert abs(float(loss["total"]) - ref[0]) <= 1e-4 * abs(ref[0]), s
+        if s == 0:
+            assert rel_err(fwd["mu_multimodal"].cpu(), g.t("mu")) < 2e-2
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        model.optimizer1.step()
+    ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    assert ok, worst
+    sd, w0 = model.state_dict(), g.weights("w0")
+    for m in range(g.M):
+        assert torch.equal(sd[f"alpha_m_list.{m}"], w0[f"alpha_m_list.{m}"])          # no gradient reaches alpha

@@ -50,3 +50,26 @@ def test_endtoend_forward_loss_grads():
     for k, r in g.grads("g0").items():
         sc = float(r.abs().max()) + 1e-12
         assert float((leaves[k].grad - r).abs().max()) <= 5e-5 * sc + 1e-7, k
+
+
+def test_mmjsd_is_poe_without_bypass():
+    """mmJSD (cVAE.py:1354-1448): the oracle's cVAE_multimodal forward / loss with combine = 'poe' reproduces the
+    reference class's losses, latent and gradients (its JSD term is identically zero)."""
+    g = Golden("mmjsd3")
+    spec = R.Spec(g.dims, g.hidden, g.Z, g.c_dim)
+    P = g.weights("w0")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    c = g.t("c")[0].long()
+    fwd = R.forward_multimodal(leaves, spec, g.xs(0), [c] * g.M, "poe", g.t("eps")[0])
+    loss = R.loss_multimodal(spec, g.xs(0), fwd)
+    loss["total"].sum().backward()
+    ref = g.z["loss0"]
+    assert _close(loss["total"], ref[0]) and _close(loss["kl"], ref[1]) and _close(loss["ll"], ref[2])
+    assert float((fwd["mu"] - g.t("mu")).abs().max()) < 1e-5
+    gref = g.grads("g0")
+    for k, v in leaves.items():
+        r = gref.get(k)
+        if k.startswith("alpha_m_list"):
+            assert r is None or float(r.abs().max()) == 0.0
+            continue
+        assert float((v.grad - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-8, k
