@@ -1354,10 +1354,24 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // ================= fusion backward: alpha gradients (gPoE) =================
   const bool fused = !(Me == 1 && J->single_bypass);
   const float klw = J->kl_weight * c.inv_b;
-  if (fused && J->combine == NM_COMBINE_GPOE) {
+  // With several experts the fusion backward (8 exponentials per element) is evaluated ONCE: the deltas of every
+  // expert go side by side into Q (expert m in columns [m 2Zs, (m+1) 2Zs) = [d mu_m | d logvar_m]), from there into
+  // the (dead) z|c slot of the workspace, and each encoder's backward below starts from a 16-byte copy of its
+  // columns.  Falls back to one evaluation per encoder when the deltas do not fit in 128 columns.
+  const bool once = fused && Me >= 2 && Me * 2 * Zs <= PW;
+  if (once || (fused && J->combine == NM_COMBINE_GPOE)) {
     relaunder(c);
     float dal[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
-    for (int e = c.tid; e < c.nrows * Z; e += WG) {
+    if (once) {                                    // zero pads of every expert's block: columns [Z, Zs) of both halves
+      const int npz = Zs - Z, cols = Me * 2 * npz;
+      const float rc_ = cols > 0 ? 1.0f / (float)cols : 0.f;
+      for (int e = c.tid; e < ROWS * cols; e += WG) {
+        const int r = idiv(e, cols, rc_), j = e - r * cols;
+        const int blk = idiv(j, npz, 1.0f / (float)npz), k = j - blk * npz;      // blk = 2 m + half
+        c.Q[r * LDP + blk * Zs + Z + k] = (__bf16)0.0f;
+      }
+    }
+    for (int e = c.tid; e < ROWS * Z; e += WG) {
       int r = idiv(e, Z, rZ), z = e - r * Z;
       Lat Lt;
       load_lat(Lt, r, z);
@@ -1366,20 +1380,31 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       float dmu_j = dz + klw * mj;
       float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
       FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+      const bool rv = r < c.nrows;
 #pragma unroll
-      for (int m = 0; m < NM_MAX_EXP; ++m) dal[m] += G.dal[m];
+      for (int m = 0; m < NM_MAX_EXP; ++m) {
+        dal[m] += rv ? G.dal[m] : 0.f;
+        if (once && m < Me) {
+          c.Q[r * LDP + m * 2 * Zs + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
+          c.Q[r * LDP + m * 2 * Zs + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
+        }
+      }
     }
-    float tot[NM_MAX_EXP];
+    if (J->combine == NM_COMBINE_GPOE) {
+      float tot[NM_MAX_EXP];
 #pragma unroll
-    for (int m = 0; m < NM_MAX_EXP; ++m) tot[m] = block_sum(c, dal[m]);
-    if (c.tid == 0) {
-      float dot = 0.f;
+      for (int m = 0; m < NM_MAX_EXP; ++m) tot[m] = block_sum(c, dal[m]);
+      if (c.tid == 0) {
+        float dot = 0.f;
 #pragma unroll
-      for (int m = 0; m < NM_MAX_EXP; ++m) dot += al[m] * tot[m];
+        for (int m = 0; m < NM_MAX_EXP; ++m) dot += al[m] * tot[m];
 #pragma unroll
-      for (int m = 0; m < NM_MAX_EXP; ++m)
-        if (m < Me) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
+        for (int m = 0; m < NM_MAX_EXP; ++m)
+          if (m < Me) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
+      }
     }
+    lds_barrier();
+    if (once) store_act(c, ws_zc, c.Q, Me * 2 * Zs);
     __syncthreads();
   }
 
@@ -1390,9 +1415,15 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const int Hh = J->H[L - 1];
     const int whp = rup(2 * Zs, 32);
     const float rwh = 1.0f / (float)whp;
-    // P <- [d mu_m | 0 | d logvar_m | 0] (pad columns first, then one fusion backward per (row, z)),
-    // Q <- last hidden activation
-    {
+    // P <- [d mu_m | 0 | d logvar_m | 0], Q <- last hidden activation
+    if (once) {                                    // this expert's columns of the saved fusion backward
+      const int segs = (2 * Zs) >> 3;              // 16-byte pieces per row
+      const float rs_ = 1.0f / (float)segs;
+      for (int p_ = c.tid; p_ < ROWS * segs; p_ += WG) {
+        const int row = idiv(p_, segs, rs_), seg = p_ - row * segs;
+        *reinterpret_cast<u32x4*>(c.P + row * LDP + seg * 8) = *(const GAS u32x4*)(ws_zc + row * PW + m * 2 * Zs + seg * 8);
+      }
+    } else {
       const int npad = whp - 2 * Z;
       const float rnp = npad > 0 ? 1.0f / (float)npad : 0.f;
       for (int e = c.tid; e < ROWS * npad; e += WG) {
