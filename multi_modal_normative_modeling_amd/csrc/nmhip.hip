@@ -1069,10 +1069,19 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const nm_modality_t& md = J->mod[m];
     const int D = md.D;
     const int Kd0 = Z + C;
-    build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
-    tr(c, 23);
-    lds_barrier();
-    if (bwd) store_act(c, ws_zc, c.P, wpad(Kd0));
+    // z | c | 1: built by the first decoder; the others reuse it when all tables carry the same covariates
+    const bool reuse_zc = J->shared_cov && M > 1;
+    if (m == 0 || !reuse_zc) {
+      build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
+      tr(c, 23);
+      lds_barrier();
+      if (bwd || reuse_zc) store_act(c, ws_zc, c.P, wpad(Kd0));
+    } else {
+      __syncthreads();                             // the first decoder's copy is complete in memory
+      load_act(c, c.P, ws_zc, wpad(Kd0));
+      tr(c, 23);
+      lds_barrier();
+    }
     tr(c, 24);
     prof(c, PH_DEC_ZC);
     // --- hidden decoder layers ---

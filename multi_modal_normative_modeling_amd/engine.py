@@ -43,6 +43,10 @@ class Table:
     def __init__(self, x, c, device=None):
         dev = require_gpu(device)
         lib = _lib.load()
+        # identity of the covariate source: tables built from the same array / tensor share their covariate block
+        self.c_key = ((c.data_ptr(), tuple(c.shape), str(c.dtype), str(c.device)) if torch.is_tensor(c) else
+                      (np.asarray(c).__array_interface__["data"][0], tuple(np.shape(c)), str(np.asarray(c).dtype)) if isinstance(c, np.ndarray)
+                      else None)
         x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
         c = torch.as_tensor(np.asarray(c) if not torch.is_tensor(c) else c)
         if x.dim() != 2 or c.dim() != 2 or x.shape[0] != c.shape[0]:
@@ -237,6 +241,8 @@ class Job:
         j.single_bypass = 1 if self.single_bypass else 0
         j.n_rows = self.tables[0].N
         j.non_linear = 1 if s.non_linear else 0
+        k0 = self.tables[0].c_key
+        j.shared_cov = 1 if (k0 is not None and all(t.c_key == k0 for t in self.tables)) else 0
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
         j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
         j.adam_off = self.t - self.step

@@ -164,3 +164,45 @@ def test_random_shape_head_models(seed):
     assert abs(float(le["classification_loss"]) - float(oe["classification_loss"])) <= 2e-2 * float(oe["classification_loss"]) + 1e-5
     assert abs(float(le["total_loss"]) - float(oe["total_loss"])) <= 5e-3 * abs(float(oe["total_loss"]))
     check(got, P, skip=tuple(f"classifier.{4 * i}.bias" for i in range(n_layers)))
+
+
+def test_distinct_covariates_per_modality():
+    """The API allows a different covariate matrix per modality (cs[i], cVAE.py:1174): then every decoder builds
+    its own z | c | 1 input (no reuse of the first decoder's copy); same covariates -> shared copy.  Both paths
+    against the oracle."""
+    import multi_modal_normative_modeling_amd as nm
+    from oracle import cvae_ref as R
+    from tests.test_gpu_fullsize import onehot
+    dims, hidden, Z, c_dim, B = [40, 55, 33], [32, 24], 6, 5, 100
+    g = torch.Generator().manual_seed(77)
+    spec = nm.ModelSpec(dims, hidden, Z, c_dim, True)
+    P = nm.ParamLayout(spec).init_reference_rule(7)
+    xs = [torch.randn(B, d, generator=g) for d in dims]
+    eps = torch.randn(B, Z, generator=g)
+    rs = R.Spec(dims, hidden, Z, c_dim, True)
+    for shared in (False, True):
+        cs = [onehot(g, B, c_dim) for _ in dims]
+        if shared:
+            cs = [cs[0]] * 3
+        job = nm.Job(spec, [nm.Table(x, c, "cuda:0") for x, c in zip(xs, cs)], combine="gpoe", state=P)
+        assert job.struct().shared_cov == (1 if shared else 0)
+        job.set_eps(eps)
+        job.enable_exports(sqerr=False, rowdev=False)
+        nm.JobSet([job]).grads(0)
+        torch.cuda.synchronize()
+        R.set_operand_rounding("bf16")
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            fwd = R.forward_multimodal(leaves, rs, xs, [c.long() for c in cs], "gpoe", eps)
+            loss = R.loss_multimodal(rs, xs, fwd)
+            loss["total"].sum().backward()
+        finally:
+            R.set_operand_rounding("fp32")
+        assert abs(float(job.loss_log[0, 2]) - float(loss["ll"])) <= 5e-6 * abs(float(loss["ll"]))
+        for m in range(3):
+            l16 = fwd["locs"][m].detach()
+            assert float((job.out_loc[m][:B].cpu() - l16).abs().max()) <= 3e-3 * float(l16.abs().max()), (shared, m)
+        got = job.grads_dict()
+        for k, v in leaves.items():
+            if v.grad is not None and float(v.grad.norm()) > 0:
+                assert float((got[k].flatten() - v.grad.flatten()).norm()) <= 4e-2 * float(v.grad.norm()) + 1e-9, (shared, k)
