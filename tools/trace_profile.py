@@ -16,9 +16,10 @@ TAGS = {0: "FL issue w", 1: "FL wait+mfma", 2: "FL barrier1", 3: "FL epilogue", 
 ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--steps", type=int, default=16)
+ap.add_argument("--procedure", default="SM-T1w_sMRI")
 a = ap.parse_args()
 cohort = prep.synthetic_cohort(n=1280, d=379)
-jobs = workload.build_sweep_jobs(cohort, "SM-T1w_sMRI", 5, a.jobs, "cuda:0")
+jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, a.jobs, "cuda:0")
 js = nm.JobSet(jobs)
 js.train(4); torch.cuda.synchronize()
 lib = _lib.load()
