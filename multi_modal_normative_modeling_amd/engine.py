@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import zlib
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -43,10 +44,10 @@ class Table:
     def __init__(self, x, c, device=None):
         dev = require_gpu(device)
         lib = _lib.load()
-        # identity of the covariate source: tables built from the same array / tensor share their covariate block
-        self.c_key = ((c.data_ptr(), tuple(c.shape), str(c.dtype), str(c.device)) if torch.is_tensor(c) else
-                      (np.asarray(c).__array_interface__["data"][0], tuple(np.shape(c)), str(np.asarray(c).dtype)) if isinstance(c, np.ndarray)
-                      else None)
+        # content key of the covariates (shape, dtype, CRC of the bytes): tables with equal keys carry the same
+        # covariate block, which lets the decoders of a model share one z | c | 1 input (nm_job_t.shared_cov)
+        c_host = c.detach().cpu().contiguous().numpy() if torch.is_tensor(c) else np.ascontiguousarray(np.asarray(c))
+        self.c_key = (tuple(c_host.shape), str(c_host.dtype), zlib.crc32(c_host.tobytes()), zlib.adler32(c_host.tobytes()))
         x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
         c = torch.as_tensor(np.asarray(c) if not torch.is_tensor(c) else c)
         if x.dim() != 2 or c.dim() != 2 or x.shape[0] != c.shape[0]:
