@@ -81,6 +81,33 @@ def kfold_indices(n: int, n_splits: int, seed: int = 42) -> List[Tuple[np.ndarra
     return out
 
 
+def generate_kfold_ids(iid_first: np.ndarray, iid_other: np.ndarray, oversample_percentage: float = 1.0,
+                       n_splits: int = 5, seed: int = 42) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """The (train_ids, test_ids) files of utils.generate_kfold_ids (utils.py:73-93) as arrays: KFold(n_splits,
+    shuffle=True, random_state=42) over concat(first group, other group); the train ids are a bootstrap resample
+    WITH replacement of the fold's train split, `np.random.choice(train_ids, size=int(len * oversample_percentage),
+    replace=True)`, drawn fold after fold from the global legacy generator the script seeds once with 42
+    (multimodal_kfold_train_cvae_supervised.py:43) -- restated with one RandomState(seed) used in the same order;
+    the test ids are the fold's test split in table order."""
+    full = np.concatenate([np.asarray(iid_first), np.asarray(iid_other)])
+    rng = np.random.RandomState(seed)
+    out = []
+    for tr, te in kfold_indices(len(full), n_splits, 42):
+        train_ids = full[tr]
+        out.append((rng.choice(train_ids, size=int(len(train_ids) * oversample_percentage), replace=True), full[te]))
+    return out
+
+
+def rows_of_ids(table_iid: np.ndarray, ids: np.ndarray) -> np.ndarray:
+    """Row indices of `pd.merge(table, ids_df, on='IID')` for a table with unique IIDs (utils.py:112-140): the merge
+    keeps the table's row order and repeats a row once per occurrence of its IID in `ids` (bootstrap duplicates)."""
+    table_iid = np.asarray(table_iid)
+    uniq, counts = np.unique(np.asarray(ids), return_counts=True)
+    cnt = dict(zip(uniq.tolist(), counts.tolist()))
+    reps = np.array([cnt.get(v, 0) for v in table_iid.tolist()], dtype=np.int64)
+    return np.repeat(np.arange(len(table_iid)), reps)
+
+
 def early_fusion(tables: Dict[str, np.ndarray], order: Sequence[str]) -> np.ndarray:
     """Column-concatenate modality tables modality-major in `order` (early_fusion_modalities.py:23-32)."""
     return np.concatenate([tables[m] for m in order], axis=1)

@@ -73,11 +73,18 @@ def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Ten
 
 
 def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int, epochs: int, device, out_dir=None,
-              lr: float = 1e-4, steps_per_launch: int = 64) -> torch.Tensor:
-    """Train the given cells concurrently, run the ROI-wise deviation pass, return the metric rows."""
+              lr: float = 1e-4, steps_per_launch: int = 64, oversample_percentage: Optional[float] = None) -> torch.Tensor:
+    """Train the given cells concurrently, run the ROI-wise deviation pass, return the metric rows.
+    `oversample_percentage` switches the training rows to the train script's own recipe (utils.generate_kfold_ids:
+    KFold over healthy + other, bootstrap resample with replacement, merged back in table order); None = the plain
+    KFold split of the regression script."""
     if not cells:
         return torch.empty(0, N_METRICS)
     folds = prep.kfold_indices(len(cohort.iid), n_folds, 42)
+    if oversample_percentage is not None:
+        hc = cohort.dia == 1
+        ids = prep.generate_kfold_ids(cohort.iid[hc], cohort.iid[~hc], oversample_percentage, n_folds)
+        folds = [(prep.rows_of_ids(cohort.iid, tr), prep.rows_of_ids(cohort.iid, te)) for tr, te in ids]
     jobs: List[Job] = []
     for c in cells:
         mods, combine = workload.procedure_modalities(c.procedure)

@@ -116,6 +116,9 @@ def test_sweep_end_to_end_small():
             assert (df.iloc[:, 1:].to_numpy() >= 0).all()
     # the loss went down over training (first vs last logged step of the first job)
     assert rows[0, 3] < 6500
+    # the train script's own fold recipe (bootstrap-resampled train ids, duplicates merged back in table order)
+    rows_b = sweep.run_cells(cohort, cells[:1], 5, epochs=2, device=DEV, oversample_percentage=1.2)
+    assert rows_b.shape == (1, sweep.N_METRICS) and torch.isfinite(rows_b).all()
 
 
 def _traj_ok(sd, wref, lr, steps):

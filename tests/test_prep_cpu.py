@@ -61,3 +61,25 @@ def test_synthetic_cohort_shapes_and_determinism():
     assert all(np.array_equal(a.x[m], b.x[m]) for m in a.x)
     assert (np.diff(a.iid) > 0).all()
     assert (a.dia == 0).sum() == 16
+
+
+def test_generate_kfold_ids_matches_reference_recipe():
+    """prep.generate_kfold_ids against the literal recipe of utils.py:73-93 (sklearn KFold + the global legacy
+    numpy generator seeded once), and prep.rows_of_ids against pd.merge on IID."""
+    import pandas as pd
+    from sklearn.model_selection import KFold
+    hc = np.arange(100100, 100100 + 57)
+    other = np.arange(200300, 200300 + 26)
+    got = prep.generate_kfold_ids(hc, other, oversample_percentage=1.5, n_splits=5)
+    full = pd.DataFrame({"IID": np.concatenate([hc, other])})
+    np.random.seed(42)
+    kf = KFold(n_splits=5, shuffle=True, random_state=42)
+    for fold, (tr, te) in enumerate(kf.split(full)):
+        train_ids = full.iloc[tr]["IID"]
+        ref_train = np.random.choice(train_ids, size=int(len(train_ids) * 1.5), replace=True)
+        assert np.array_equal(got[fold][0], ref_train) and np.array_equal(got[fold][1], full.iloc[te]["IID"].to_numpy())
+    table = pd.DataFrame({"IID": np.concatenate([other, hc])[::-1].copy(), "v": np.arange(83)})
+    ids_df = pd.DataFrame({"IID": got[0][0]})
+    merged = pd.merge(table, ids_df, on="IID")
+    rows = prep.rows_of_ids(table["IID"].to_numpy(), got[0][0])
+    assert np.array_equal(merged["v"].to_numpy(), table["v"].to_numpy()[rows])
