@@ -295,3 +295,35 @@ def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int]
         row.update({name: float(cm[i, c]) for c, name in enumerate(metrics.CONFUSION_COLUMNS)})
         out.append(row)
     return out
+
+
+def test_fold(job: Job, cohort: prep.SyntheticCohort, train_rows: np.ndarray, test_rows: np.ndarray, modalities: Sequence[str],
+              combine: str, device, out_dir=None, roi_columns: Optional[Dict[str, Sequence[str]]] = None):
+    """One fold of multimodal_kfold_test_cvae_supervised.py:64-153 for a trained model: per modality a RobustScaler
+    fit on the fold's train rows and applied to the test rows (:86-92), covariates re-binned on the TEST rows
+    (:94-99), `pred_recon` (joint latent, sampled z; one workgroup per 256-row tile) and
+    `reconstruction_deviation_multimodal`, then the five CSV kinds per modality (:121-153).  Returns
+    {modality: per-subject reconstruction error} (what the group analysis averages and scores)."""
+    xs = []
+    for m in modalities:
+        src = cohort.x[m] if m in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
+        center, scale = prep.robust_scaler_fit(src[train_rows])
+        xs.append(prep.robust_scaler_transform(src[test_rows], center, scale).astype(np.float32))
+    cov = prep.one_hot_covariates(cohort.age[test_rows], cohort.gender[test_rows])
+    tables = [Table(x, cov, device) for x in xs]
+    ev = Job(job.spec, tables, combine=combine, state=job.state_dict(), seed=job.seed + 31, n_tiles_ws=tables[0].n_tiles)
+    ev.enable_exports(loc=True, sqerr=False, rowdev=True, latent=False)
+    JobSet([ev]).forward()
+    torch.cuda.synchronize(device)
+    n = len(test_rows)
+    errors = {}
+    for i, m in enumerate(modalities):
+        x_hat = ev.out_loc[i][:n].cpu().numpy()
+        errors[m] = ev.out_rowdev[i][:n].cpu().numpy()
+        if out_dir is not None:
+            import pandas as pd
+            meta = pd.DataFrame({"participant_id": cohort.iid[test_rows], "DIA": cohort.dia[test_rows],
+                                 "AGE": cohort.age[test_rows], "PTGENDER": cohort.gender[test_rows]})
+            cols = list(roi_columns[m]) if roi_columns and m in roi_columns else [f"{m}_{k}" for k in range(xs[i].shape[1])]
+            io.write_test_csvs(Path(out_dir) / m, m, meta, cols, xs[i], x_hat)
+    return errors

@@ -538,3 +538,34 @@ def test_mmjsd_matches_reference():
     sd, w0 = model.state_dict(), g.weights("w0")
     for m in range(g.M):
         assert torch.equal(sd[f"alpha_m_list.{m}"], w0[f"alpha_m_list.{m}"])          # no gradient reaches alpha
+
+
+def test_test_script_fold_outputs():
+    """sweep.test_fold = one fold of the reference's test script: the five CSV kinds per modality with its column
+    layouts, mutually consistent values (error = ROI-mean of the ROI-wise error = mean (normalized - reconstruction)^2)
+    and the device row deviations equal to them."""
+    cohort = prep.synthetic_cohort(n=320, d=116)
+    folds = prep.kfold_indices(320, 5, 42)
+    tr, te = folds[2]
+    mods = list(prep.HCP_MODALITIES)
+    xs, cov = prep.fold_train_tables(cohort, mods, tr)
+    spec = nm.ModelSpec([116] * 3, [110, 110], 10, 29)
+    job = nm.Job(spec, [nm.Table(x, cov, DEV) for x in xs], combine="gpoe", seed=3)
+    nm.JobSet([job]).train(20)
+    with tempfile.TemporaryDirectory() as d:
+        errs = sweep.test_fold(job, cohort, tr, te, mods, "gpoe", DEV, out_dir=d)
+        for m in mods:
+            base = f"{d}/{m}"
+            norm = pd.read_csv(f"{base}/normalized_{m}.csv")
+            rec = pd.read_csv(f"{base}/reconstruction_{m}.csv")
+            err = pd.read_csv(f"{base}/reconstruction_error_{m}.csv")
+            roi = pd.read_csv(f"{base}/reconstruction_error_roi_{m}.csv")
+            fi = pd.read_csv(f"{base}/deviation_as_feature_importance_{m}.csv")
+            meta = ["participant_id", "DIA", "AGE", "PTGENDER"]
+            assert list(norm.columns[:4]) == meta and list(err.columns) == meta + ["Reconstruction error"]
+            assert list(fi.columns[4:]) == [str(k) for k in range(1, 117)] and len(norm) == len(te) == 64
+            assert (norm["participant_id"].to_numpy() == cohort.iid[te]).all()
+            sq = (norm.iloc[:, 4:].to_numpy() - rec.iloc[:, 4:].to_numpy()) ** 2
+            np.testing.assert_allclose(roi.iloc[:, 4:].to_numpy(), sq, rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(err["Reconstruction error"].to_numpy(), sq.mean(axis=1), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(errs[m], sq.mean(axis=1), rtol=1e-3, atol=1e-6)
