@@ -439,6 +439,16 @@ class JobSet:
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    def assert_finite(self):
+        """Failure detection, once per epoch / run rather than per step (the reference prints NaNs from inside
+        its hot loop, cVAE.py:1169-1172): one device reduction over every job's loss ring; raises NmError naming
+        the first job whose log holds a non-finite value."""
+        logs = torch.stack([j.loss_log for j in self.jobs])
+        ok = torch.isfinite(logs).flatten(1).all(dim=1)
+        if not bool(ok.all()):
+            bad = int((~ok).nonzero()[0])
+            raise _lib.NmError(f"non-finite loss in job {bad} of {len(self.jobs)} (step {self.jobs[bad].step})")
+
 
 def adam_step(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, t: int, lr=1e-4,
               betas=(0.9, 0.999), eps=1e-8):

@@ -38,20 +38,22 @@ def write_test_csvs(out_dir, dataset_name: str, covariates: pd.DataFrame, roi_co
     out_dir.mkdir(parents=True, exist_ok=True)
     cov = covariates[META_COLS].copy()
     paths = {}
-    normalized = cov.copy()
-    normalized[list(roi_columns)] = x
+    cov = cov.reset_index(drop=True)
+
+    def with_rois(values):                      # same frame as `df[columns_name] = values` (…test….py:123-124), built in one go
+        return pd.concat([cov, pd.DataFrame(np.asarray(values), columns=list(roi_columns))], axis=1)
+
+    normalized = with_rois(x)
     paths["normalized"] = out_dir / f"normalized_{dataset_name}.csv"
     normalized.to_csv(paths["normalized"], index=False)
-    recon = cov.copy()
-    recon[list(roi_columns)] = x_hat
+    recon = with_rois(x_hat)
     paths["reconstruction"] = out_dir / f"reconstruction_{dataset_name}.csv"
     recon.to_csv(paths["reconstruction"], index=False)
     err = cov.copy()
     err["Reconstruction error"] = np.sum((x - x_hat) ** 2, axis=1) / x.shape[1]
     paths["reconstruction_error"] = out_dir / f"reconstruction_error_{dataset_name}.csv"
     err.to_csv(paths["reconstruction_error"], index=False)
-    err_roi = cov.copy()
-    err_roi[list(roi_columns)] = (x - x_hat) ** 2
+    err_roi = with_rois((x - x_hat) ** 2)
     paths["reconstruction_error_roi"] = out_dir / f"reconstruction_error_roi_{dataset_name}.csv"
     err_roi.to_csv(paths["reconstruction_error_roi"], index=False)
     fi = err_roi.rename(columns=dict(zip(roi_columns, map(str, range(1, len(roi_columns) + 1)))))

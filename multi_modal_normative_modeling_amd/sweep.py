@@ -108,6 +108,7 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
             js.train(k)
             done += k
         total_steps += n * len(idxs)
+        js.assert_finite()
     torch.cuda.synchronize(device)
     sps = total_steps / max(time.perf_counter() - t0, 1e-9)
     # deviation pass per cell; the per-subject score (mean over modalities of the ROI-mean deviation) stays on
@@ -201,6 +202,7 @@ def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[in
     t0 = time.perf_counter()
     js.train_regression(n)
     torch.cuda.synchronize(device)
+    js.assert_finite()
     sps = n * len(jobs) / max(time.perf_counter() - t0, 1e-9)
     results = []
     for k, j, sc in zip(folds_to_run, jobs, scalers):
@@ -269,6 +271,7 @@ def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int]
     t0 = time.perf_counter()
     js.train_endtoend(n)
     torch.cuda.synchronize(device)
+    js.assert_finite()
     sps = n * len(jobs) / max(time.perf_counter() - t0, 1e-9)
     preds, labs, finals = [], [], []
     for k, j, sc in zip(folds_to_run, jobs, scalers):

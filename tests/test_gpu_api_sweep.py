@@ -569,3 +569,20 @@ def test_test_script_fold_outputs():
             np.testing.assert_allclose(roi.iloc[:, 4:].to_numpy(), sq, rtol=1e-4, atol=1e-6)
             np.testing.assert_allclose(err["Reconstruction error"].to_numpy(), sq.mean(axis=1), rtol=1e-4, atol=1e-6)
             np.testing.assert_allclose(errs[m], sq.mean(axis=1), rtol=1e-3, atol=1e-6)
+
+
+def test_non_finite_loss_is_detected():
+    """JobSet.assert_finite: a model driven to overflow (absurd learning rate) is reported, healthy ones pass."""
+    g = Golden("mm1_small")
+    from tests.hip_harness import make_job
+    good, bad = make_job(g, 0), make_job(g, 0)
+    bad.lr = 1e30
+    bad.touch()
+    js = nm.JobSet([good, bad])
+    js.train(1)
+    js.assert_finite()                                   # the first step's loss is still the initial one
+    js.train(6)
+    torch.cuda.synchronize()
+    with pytest.raises(nm._lib.NmError, match="job 1"):
+        js.assert_finite()
+    nm.JobSet([good]).assert_finite()
