@@ -33,7 +33,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--jobs", type=int, default=256, help="independent models per GPU (one workgroup each)")
     ap.add_argument("--procedure", default="SE-gPoE", help="SM-<modality> | SE-<combine> | UCA-<combine>")
-    ap.add_argument("--steps-per-launch", type=int, default=32)
+    ap.add_argument("--steps-per-launch", type=int, default=128,
+                    help="train steps inside one persistent launch (the timed K steps run as ceil(K / this) launches)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
     ap.add_argument("--subjects", type=int, default=1280)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(affinity, 16))")
