@@ -97,6 +97,9 @@ typedef struct nm_job {
   int32_t single_bypass;  /* 1: M == 1 skips fusion (cVAE.py:1146-1147)                  */
   int32_t n_rows;         /* valid rows in the tables                                    */
   int32_t non_linear;     /* 1: LeakyReLU(0.01) between layers (cVAE.py:166-167)         */
+  int32_t dephase;        /* launches of >= 64 steps: workgroup b first sleeps (b mod 8) * dephase * 8128 cycles,
+                             so that identical models do not run their HBM-heavy phases in lockstep (0 = off;
+                             about 1/8 of a step is the useful value)                                       */
   int32_t shared_cov;     /* 1: every modality's table carries the same covariate block: the decoder input
                              z | c | 1 is built once per step and reused by the other decoders            */
   int32_t loss_cap;       /* rows of loss_log; step s writes row s % loss_cap            */

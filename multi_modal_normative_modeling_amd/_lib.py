@@ -58,7 +58,7 @@ class NmJob(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("M_enc", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("Z", C.c_int32),
         ("H", C.c_int32 * NM_MAX_HID),
-        ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32), ("shared_cov", C.c_int32),
+        ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32), ("dephase", C.c_int32), ("shared_cov", C.c_int32),
         ("loss_cap", C.c_int32), ("eps_cap", C.c_int32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_off", C.c_int64),

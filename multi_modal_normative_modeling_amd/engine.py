@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import zlib
 from typing import Dict, List, Optional, Sequence
 
@@ -113,6 +114,7 @@ class Job:
         self.out_logits: Optional[torch.Tensor] = None
         self.cls_train, self.cls_use_mu = True, False
         self.cls_dropout, self.cls_margin, self.cls_w_ce, self.cls_w_contrast = 0.0, 1.0, 1.0, 0.1
+        self.dephase = os.environ.get("NMHIP_DEPHASE", "1") != "0"      # see nm_job_t.dephase
         self.reg_lambda = 1.0                         # regression head (kind == "regression")
         self.fi_target: Optional[torch.Tensor] = None # [rows_alloc]
         self.out_fi_pred: Optional[torch.Tensor] = None
@@ -242,6 +244,9 @@ class Job:
         j.single_bypass = 1 if self.single_bypass else 0
         j.n_rows = self.tables[0].N
         j.non_linear = 1 if s.non_linear else 0
+        # one eighth of a train step in units of s_sleep(127) (~8128 cycles); a step costs ~5.3 cycles per parameter
+        # with the chip full (measured on 118 k .. 642 k parameter models)
+        j.dephase = int(round(self.layout.n_params * 5.3 / 8 / 8128)) if self.dephase else 0
         k0 = self.tables[0].c_key
         j.shared_cov = 1 if (k0 is not None and all(t.c_key == k0 for t in self.tables)) else 0
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
