@@ -582,6 +582,29 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
   tr(c, 12);
 }
 
+// Both encoder heads as ONE LDS tile [2 Zs][LDP]: rows [0, Z) = enc_mean_layer, rows [Zs, Zs + Z) =
+// enc_logvar_layer, zeros elsewhere (2 Zs <= 128 rows).  Two block copies of up to 64 rows each.
+__device__ __forceinline__ void stage_heads(const Ctx& c, __bf16* dst, gcf32 Wmu, gcf32 Wlv, int Z, int K, int Zs) {
+  const int Kp = kpitch(K);
+  WBlk<64> a, b;
+  wblk_load<64>(c, a, Wmu, Z, Kp, 0, 0);
+  wblk_load<64>(c, b, Wlv, Z, Kp, 0, 0);
+  // a 64-row block covers Zs <= 64 rows of each head; rows >= Z are written as zeros
+  const int rows = Zs;                          // rows of each half actually used
+#pragma unroll
+  for (int j = 0; j < (64 * 128 / 4) / WG; ++j) {
+    const int p = c.tid + j * WG, lr = p >> 5, lc = (p & 31) * 4;
+    if (lr < rows) {
+      const bool ok = lr < Z && lc < Kp;
+      bf16x4 pa, pb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pa[i] = (__bf16)(ok ? a.v[j][i] : 0.f); pb[i] = (__bf16)(ok ? b.v[j][i] : 0.f); }
+      *reinterpret_cast<bf16x4*>(dst + lr * LDP + lc) = pa;
+      *reinterpret_cast<bf16x4*>(dst + (Zs + lr) * LDP + lc) = pb;
+    }
+  }
+}
+
 // ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
 __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, gcf32 Wlv, gcf32 blv, int Z, int K,
                                           gf32 mu_out, gf32 lv_out, int Zs) {
@@ -589,41 +612,30 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, g
   relaunder(c);
   const int ksteps = wpad(K) / 32;
   const int nzt = Zs / 16;
-  for (int ft = c.wn; ft < nzt; ft += 4) {
+  stage_heads(c, c.Q, Wmu, Wlv, Z, K, Zs);          // Q is free during the forward chain
+  lds_barrier();
+  // unit = (feature tile, row tile of the wave's row half): the 4 waves of a row half share them round-robin,
+  // so all 8 waves work even when the latent fits one feature tile
+  for (int u = c.wn; u < nzt * RT; u += NWN) {
+    const int ft = u / RT, rt = u - ft * RT;
     const int f0 = ft * 16 + 4 * c.g;
-    f32x4 am[RT], al[RT];
-    f32x4 b0, b1;
+    f32x4 am, al;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float x0 = bmu[min(f0 + i, Z - 1)], x1 = blv[min(f0 + i, Z - 1)];
-      b0[i] = (f0 + i < Z) ? x0 : 0.f;
-      b1[i] = (f0 + i < Z) ? x1 : 0.f;
+      am[i] = (f0 + i < Z) ? x0 : 0.f;
+      al[i] = (f0 + i < Z) ? x1 : 0.f;
     }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { am[rt] = b0; al[rt] = b1; }
-    bf16x8 fm[4], fl[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      fm[ks] = w_frag(Wmu, Z, K, ft * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
-      fl[ks] = w_frag(Wlv, Z, K, ft * 16 + c.c16, min(ks, ksteps - 1) * 32 + 8 * c.g);
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const bf16x8 fm = lds_frag(c.Q, LDP, ft * 16 + c.c16, ks * 32 + 8 * c.g);
+      const bf16x8 fl = lds_frag(c.Q, LDP, Zs + ft * 16 + c.c16, ks * 32 + 8 * c.g);
+      const bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+      am = mfma(fm, a, am);
+      al = mfma(fl, a, al);
     }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < ksteps) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
-          am[rt] = mfma(fm[ks], a, am[rt]);
-          al[rt] = mfma(fl[ks], a, al[rt]);
-        }
-      }
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      int r = c.wm * WROWS + rt * 16 + c.c16;
-      *(GAS f32x4*)(mu_out + r * Zs + f0) = am[rt];      // features >= Z are exactly 0 (masked weights, zero bias)
-      *(GAS f32x4*)(lv_out + r * Zs + f0) = al[rt];
-    }
+    const int r = c.wm * WROWS + rt * 16 + c.c16;
+    *(GAS f32x4*)(mu_out + r * Zs + f0) = am;        // features >= Z are exactly 0 (zero weight rows, zero bias)
+    *(GAS f32x4*)(lv_out + r * Zs + f0) = al;
   }
   tr(c, 13);
   __syncthreads();
@@ -692,29 +704,6 @@ __device__ __forceinline__ void dgrad_staged(const Ctx& cc, f32x4 (&acc)[2][RT],
   wblk_store<128>(c, wsg, c.Q, LDP, N, Kp, 0, 0);
   lds_barrier();
   dgrad_tile(c, acc, A, 0, c.Q, LDP, wpad(N) / 32);
-}
-
-// dgrad through the two encoder heads: P columns [0,Zs) = d mu, [Zs,2Zs) = d logvar
-__device__ __forceinline__ void dgrad_heads(const Ctx& cc, f32x4 (&acc)[2][RT], gcf32 Wmu, gcf32 Wlv, int Z, int K,
-                                            int Zs) {
-  Ctx c = cc;
-  relaunder(c);
-  const int nsteps = rup(2 * Zs, 32) / 32;
-  for (int s = 0; s < nsteps; ++s) {
-    bf16x8 wf[2];
-    int nn0 = s * 32 + 8 * c.g;              // 8-aligned, Zs is a multiple of 16: never straddles
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      int k = (c.wn + 4 * t) * 16 + c.c16;
-      wf[t] = (nn0 < Zs) ? w_frag_t(Wmu, Z, K, nn0, k) : w_frag_t(Wlv, Z, K, nn0 - Zs, k);
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, s * 32 + 8 * c.g);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
-    }
-  }
 }
 
 // P[r][k] = acc[k][r] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
@@ -1456,16 +1445,19 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       }
     }
     tr(c, 37);
+    // dgrad through both heads from one staged tile (rows = [d mu | d logvar] columns of P), then Q <- activation
+    stage_heads(c, c.Q, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
+    lds_barrier();
+    prof(c, PH_ENCB_PREP);
+    f32x4 acc[2][RT];
+    zero_acc(acc);
+    dgrad_tile(c, acc, c.P, 0, c.Q, LDP, (2 * Zs) / 32);
+    lds_barrier();                                  // tile fully read
+    prof(c, PH_ENCB_HEADS_DGRAD);
     load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW, wpad(Hh));
     tr(c, 38);
     lds_barrier();
     tr(c, 39);
-    prof(c, PH_ENCB_PREP);
-    f32x4 acc[2][RT];
-    zero_acc(acc);
-    dgrad_heads(c, acc, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
-    lds_barrier();
-    prof(c, PH_ENCB_HEADS_DGRAD);
     wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.mu_w, md.mu_b);
     wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.lv_w, md.lv_b);
     prof(c, PH_ENCB_HEADS_WGRAD);
