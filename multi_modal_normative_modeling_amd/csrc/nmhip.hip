@@ -428,14 +428,36 @@ __device__ __forceinline__ void w0chunk_store(const Ctx& c, const W0Stage& s, __
 // columns D .. D+C hold c | 1), then the z columns from the latent workspace.
 __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_modality_t& md, gcf32 mu_j, gcf32 es, int Z,
                                          int C, int Zs) {
-  const int wz = wpad(Z + C), wc = wz - Z;
-  const float rwc = 1.0f / (float)wc, rz = 1.0f / (float)Z;
-  gcbf16 xb = (gcbf16)asg(md.xb);
-#pragma unroll 4
-  for (int e = c.tid; e < ROWS * wc; e += WG) {
-    int r = idiv(e, wc, rwc), j = e - r * wc;
-    __bf16 v = xb[(int64_t)(c.row0 + r) * md.Kx + md.D + min(j, C)];
-    dst[r * LDP + Z + j] = (j <= C) ? v : (__bf16)0.0f;
+  const int wz = wpad(Z + C);
+  const float rz = 1.0f / (float)Z;
+  const GAS uint16_t* xb = asg(md.xb);
+  // covariates and the ones column: 16-byte pieces of the packed table starting at the aligned column at or
+  // below D (the row pitch Kx is a multiple of 32 and >= D + C + 1, so every piece is inside the row), scattered
+  // into the unaligned destination with 2-byte LDS stores
+  {
+    const int c0 = md.D & ~7;
+    const int npc = (md.D + C + 1 - c0 + 7) >> 3;
+    const float rnp = 1.0f / (float)npc;
+    for (int p = c.tid; p < ROWS * npc; p += WG) {
+      const int r = idiv(p, npc, rnp), col0 = c0 + 8 * (p - r * npc);
+      const u32x4 v = *(const GAS u32x4*)(xb + (int64_t)(c.row0 + r) * md.Kx + col0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = col0 + i - md.D;
+        const uint16_t h = (uint16_t)(v[i >> 1] >> (16 * (i & 1)));
+        if (j >= 0 && j <= C) reinterpret_cast<uint16_t*>(dst)[r * LDP + Z + j] = h;
+      }
+    }
+  }
+  {                                                 // zero pad columns (Z + C, wz)
+    const int nz = wz - (Z + C + 1);
+    if (nz > 0) {
+      const float rnz = 1.0f / (float)nz;
+      for (int e = c.tid; e < ROWS * nz; e += WG) {
+        const int r = idiv(e, nz, rnz);
+        dst[r * LDP + Z + C + 1 + (e - r * nz)] = (__bf16)0.0f;
+      }
+    }
   }
 #pragma unroll 4
   for (int e = c.tid; e < ROWS * Z; e += WG) {
