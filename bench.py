@@ -175,7 +175,7 @@ def main():
         for b in range(jobs[0].batches_per_epoch):
             lo, hi = b * 256, min(N, (b + 1) * 256)
             xes = [t.x_f32[lo:hi, :t.D].cpu().contiguous() for t in jobs[0].tables]
-            c = jobs[0].tables[0].xb[lo:hi, jobs[0].tables[0].D:jobs[0].tables[0].D + spec.c_dim].float().cpu()
+            c = jobs[0].tables[0].cz[lo:hi, :spec.c_dim].float().cpu()
             batches.append((xes, [c.long()] * len(xes)))
         sps, n = time_cpu_steps(stepper, batches, budget_s=args.cpu_budget)
         out["cpu_baseline"] = {"value": round(sps, 2), "unit": "steps/s", "cores": torch.get_num_threads(),

@@ -57,19 +57,31 @@ enum {
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the
  * job's flat fp32 parameter buffer.  Offsets are in floats; tensors keep the reference's own
- * shapes and row-major [out][in] layout (nn.Linear), so a state_dict copies in and out. */
+ * shapes; a weight matrix [N][K] is stored as 16 x 16 fp32 tiles, [ceil(N/16)][ceil(K/16)][16][16], zero padded
+ * (1 KiB per tile: the Adam sweep of a tile is one lane-linear 16-byte access per lane); vectors are stored plain.
+ * ParamLayout (layout.py) converts to and from the reference's state_dict. */
 typedef struct nm_modality {
   int32_t D;              /* ROI features of this modality                               */
-  int32_t Kx;             /* row pitch of xb in elements: multiple of 32, >= D + C + 1   */
+  int32_t Kx;             /* logical width of the packed operand row x | c | 1 | 0: multiple of 32, >= D + C + 1 */
   int32_t x_pitch;        /* row pitch of x_f32 in floats: multiple of 4, >= D           */
+  int32_t Cz;             /* row pitch of cz in elements: multiple of 8, >= C + 1         */
   const float*    x_f32;  /* [rows_alloc][x_pitch] fp32 inputs (residual / NLL side)     */
-  const uint16_t* xb;     /* [rows_alloc][Kx]  bf16: x | c | 1 | 0...   (MFMA operand)   */
+  const uint16_t* xb;     /* bf16 MFMA operand x | c | 1 | 0 as LDS images: [rows_alloc / 256][ceil(Kx / 64)][256][72]
+                             (64-column chunks of 256-row tiles, row pitch 72 = the LDS pitch: one chunk is 36 KiB of
+                             contiguous memory that an LDS-DMA copy lands in LDS without touching a register)       */
+  const uint16_t* cz;     /* [rows_alloc][Cz] bf16: c | 1 | 0  (covariate block of the decoder input z | c | 1)    */
   int64_t enc_w[NM_MAX_HID], enc_b[NM_MAX_HID];   /* encoder_layers.{i}.weight/.bias      */
   int64_t mu_w, mu_b, lv_w, lv_b;                 /* enc_mean_layer / enc_logvar_layer    */
   int64_t logvar_out;                             /* decoder logvar_out [1][D]            */
   int64_t dec_w[NM_MAX_HID], dec_b[NM_MAX_HID];   /* decoder_layers.{i}                   */
   int64_t out_w, out_b;                           /* decoder_mean_layer                   */
   int64_t alpha;                                  /* alpha_m_list.{m} or -1               */
+  /* byte offsets of this modality's bf16 shadow images inside job.wsh (filled by nm_fill_shadow): the weights the
+   * forward / dgrad GEMMs read, laid out exactly as the LDS tiles, rewritten by the Adam sweep              */
+  int64_t enc_s[NM_MAX_HID];                      /* [0]: ceil(Kx/64) chunk images [128][72] + bias; others [128][136] + bias */
+  int64_t heads_s;                                /* [128][136]: rows [0,Z) mean head, [Zs,Zs+Z) logvar head; + biases */
+  int64_t dec_s[NM_MAX_HID];                      /* [128][136] + bias                                              */
+  int64_t out_s;                                  /* ceil(D/64) chunk blobs: [64][136] + bias[64] + logvar_out[64]   */
   /* optional per-row exports (NM_F_EXPORT), indexed by absolute table row; may be NULL */
   float* out_loc;         /* [rows_alloc][x_pitch]  decoder mean x_hat (pad columns 0)   */
   float* out_sqerr;       /* [rows_alloc][x_pitch]  (x - x_hat)^2        (pad columns 0)   */
@@ -97,9 +109,9 @@ typedef struct nm_job {
   int32_t single_bypass;  /* 1: M == 1 skips fusion (cVAE.py:1146-1147)                  */
   int32_t n_rows;         /* valid rows in the tables                                    */
   int32_t non_linear;     /* 1: LeakyReLU(0.01) between layers (cVAE.py:166-167)         */
-  int32_t dephase;        /* launches of >= 64 steps: workgroup b first sleeps (b mod 8) * dephase * 8128 cycles,
-                             so that identical models do not run their HBM-heavy phases in lockstep (0 = off;
-                             about 1/8 of a step is the useful value)                                       */
+  int32_t dephase;        /* launches of >= 64 steps: the job's workgroup first sleeps dephase * 8128 cycles, so that
+                             identical models do not run their HBM-heavy phases in lockstep (0 = off; the host spreads
+                             the jobs of a launch over one step's worth of cycles, engine.py)                        */
   int32_t shared_cov;     /* 1: every modality's table carries the same covariate block: the decoder input
                              z | c | 1 is built once per step and reused by the other decoders            */
   int32_t loss_cap;       /* rows of loss_log; step s writes row s % loss_cap            */
@@ -116,6 +128,8 @@ typedef struct nm_job {
                              to use the in-kernel counter-based generator              */
   uint64_t seed;          /* generator key when eps == NULL                              */
   float*  loss_log;       /* [loss_cap][NM_LOSS_STRIDE] (may be NULL)                    */
+  void*   wsh;            /* bf16 shadow images of the weights, nm_fill_shadow() bytes, zero-initialised by the
+                             caller and brought up to date by nm_sync_shadow() whenever the HOST changed params    */
   void*   workspace;      /* nm_workspace_bytes() per concurrently running tile          */
   int64_t workspace_stride; /* bytes between the workspaces of consecutive tiles        */
   float*  out_mu;         /* NM_F_EXPORT: [rows_alloc][Z] joint mu      (may be NULL)    */
@@ -159,6 +173,15 @@ typedef struct nm_job {
 #define NM_LOSS_REG   12   /* MSE of the regression head (nm_head_regression) */
 #define NM_LOSS_CE    13   /* cross entropy of the classifier head (nm_head_classifier) */
 #define NM_LOSS_CONTRAST 14 /* contrastive hinge of the classifier head */
+
+/* Fill the shadow-image offsets (mod[m].enc_s / heads_s / dec_s / out_s) of a HOST descriptor from its shapes
+ * and return the bytes job.wsh must hold (host-side helper, no device access); negative = argument error. */
+int64_t nm_fill_shadow(nm_job_t* job_host);
+
+/* Rebuild every job's shadow images from its fp32 parameters (one workgroup per job).  Call after the host wrote
+ * job.params (initialisation, load_state_dict, an external optimizer step); launches that apply Adam keep the
+ * images current themselves. */
+int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream);
 
 /* Bytes of workspace one tile of a job needs (host-side helper, no device access). */
 int64_t nm_workspace_bytes(const nm_job_t* job_host);
@@ -226,11 +249,13 @@ int nm_deviation(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, v
 int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
                  float lr, float beta1, float beta2, float eps, int64_t t, void* stream);
 
-/* Build the bf16 operand table xb[rows_alloc][Kx] = x | c | 1 | 0 from fp32 x [n_rows][D] and
+/* Build the bf16 operand images xb (layout: nm_modality_t.xb) = x | c | 1 | 0 from fp32 x [n_rows][D] and
  * fp32 c [n_rows][C]; rows >= n_rows are zero-filled.  x_f32_out [rows_alloc][x_pitch] receives the
- * zero-padded fp32 copy (x_pitch = D rounded up to a multiple of 4). */
+ * zero-padded fp32 copy (x_pitch = D rounded up to a multiple of 4), cz_out [rows_alloc][Cz] the covariate
+ * block c | 1 | 0 (Cz a multiple of 8, >= C + 1).  nm_xb_elems() = elements xb must hold. */
+int64_t nm_xb_elems(int rows_alloc, int Kx);
 int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx,
-                  uint16_t* xb, float* x_f32_out, int x_pitch, void* stream);
+                  uint16_t* xb, float* x_f32_out, int x_pitch, uint16_t* cz_out, int Cz, void* stream);
 
 /* Debug / unit-test entry: C[M][N] = A[M][K] * B[N][K]^T through the kernel's own fragment
  * loaders.  mode 0: A row-major via LDS, B fp32 weights (forward form); mode 1: dgrad form

@@ -41,14 +41,15 @@ LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 
 class NmModality(C.Structure):
     _fields_ = [
-        ("D", C.c_int32), ("Kx", C.c_int32), ("x_pitch", C.c_int32),
-        ("x_f32", C.c_void_p), ("xb", C.c_void_p),
+        ("D", C.c_int32), ("Kx", C.c_int32), ("x_pitch", C.c_int32), ("Cz", C.c_int32),
+        ("x_f32", C.c_void_p), ("xb", C.c_void_p), ("cz", C.c_void_p),
         ("enc_w", C.c_int64 * NM_MAX_HID), ("enc_b", C.c_int64 * NM_MAX_HID),
         ("mu_w", C.c_int64), ("mu_b", C.c_int64), ("lv_w", C.c_int64), ("lv_b", C.c_int64),
         ("logvar_out", C.c_int64),
         ("dec_w", C.c_int64 * NM_MAX_HID), ("dec_b", C.c_int64 * NM_MAX_HID),
         ("out_w", C.c_int64), ("out_b", C.c_int64),
         ("alpha", C.c_int64),
+        ("enc_s", C.c_int64 * NM_MAX_HID), ("heads_s", C.c_int64), ("dec_s", C.c_int64 * NM_MAX_HID), ("out_s", C.c_int64),
         ("out_loc", C.c_void_p), ("out_sqerr", C.c_void_p), ("out_rowdev", C.c_void_p),
         ("dloc_extra", C.c_void_p), ("dloc_rowcoef", C.c_void_p),
     ]
@@ -65,7 +66,7 @@ class NmJob(C.Structure):
         ("kl_weight", C.c_float), ("ll_weight", C.c_float),
         ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("grads", C.c_void_p),
         ("eps", C.c_void_p), ("seed", C.c_uint64),
-        ("loss_log", C.c_void_p), ("workspace", C.c_void_p), ("workspace_stride", C.c_int64),
+        ("loss_log", C.c_void_p), ("wsh", C.c_void_p), ("workspace", C.c_void_p), ("workspace_stride", C.c_int64),
         ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p), ("dz_extra", C.c_void_p),
         ("reg_head", C.c_int32), ("reg_lambda", C.c_float), ("reg_w", C.c_int64 * 3), ("reg_b", C.c_int64 * 3),
         ("fi_target", C.c_void_p), ("out_fi_pred", C.c_void_p),
@@ -104,6 +105,11 @@ def load():
     lib.nm_status_string.argtypes = [C.c_int]
     lib.nm_abi_sizes.argtypes = [C.POINTER(i64), C.POINTER(i64)]
     lib.nm_workspace_bytes.restype = i64
+    lib.nm_fill_shadow.restype = i64
+    lib.nm_fill_shadow.argtypes = [C.POINTER(NmJob)]
+    lib.nm_sync_shadow.argtypes = [vp, i32, vp]
+    lib.nm_xb_elems.restype = i64
+    lib.nm_xb_elems.argtypes = [i32, i32]
     lib.nm_workspace_bytes.argtypes = [C.POINTER(NmJob)]
     lib.nm_validate_job.argtypes = [C.POINTER(NmJob)]
     for name in ("nm_launch", "nm_launch_scalar_tr"):
@@ -118,7 +124,7 @@ def load():
     lib.nm_posthoc_metrics.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nm_confusion_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
-    lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     lib.nm_prof_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
     lib.nm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
@@ -135,6 +141,7 @@ EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
+    "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems",
 ]
 
 

@@ -87,7 +87,9 @@ class _Adam:
         self.t += 1
         adam_step(m._job.params, m._pending, m._job.adam_m, m._job.adam_v, self.t, lr=g["lr"], betas=g["betas"],
                   eps=g["eps"])
+        m.layout.kernel_to_nat(m._job.params, m._flat.data)     # the module's parameter views follow
         m._job.t = self.t
+        m._job.params_changed()
         m._job.touch()
 
 
@@ -98,7 +100,9 @@ class _Base(nn.Module):
         self._device = None
         self._lr = learning_rate
         self._kl_weight = kl_weight
-        self._flat = nn.Parameter(self.layout.flatten(self.layout.init_reference_rule(
+        # "natural" flat buffer (tensors row-major, back to back): the module tree below holds VIEWS into it; the
+        # kernels' own tiled copy (Job.params) is refreshed from it before every launch
+        self._flat = nn.Parameter(self.layout.nat_flatten(self.layout.init_reference_rule(
             int(torch.initial_seed() % (2 ** 31)))), requires_grad=False)
         self._job: Optional[Job] = None
         self._grads_ready = False
@@ -109,7 +113,7 @@ class _Base(nn.Module):
 
     # -- module tree with the reference's parameter names (views into the flat buffer) --------------
     def _views(self):
-        return {k: v for k, v in self.layout.unflatten(self._flat.data).items()}
+        return self.layout.nat_views(self._flat.data)
 
     def _build_tree(self):
         v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
@@ -149,9 +153,7 @@ class _Base(nn.Module):
         return {n: t.detach().cpu().clone() for n, t in self._views().items()}
 
     def load_state_dict(self, state, strict: bool = True):
-        self._flat.data.copy_(self.layout.flatten(state, device=self._flat.device))
-        if self._job is not None:
-            self._job.params.copy_(self._flat.data)
+        self._flat.data.copy_(self.layout.nat_flatten(state, device=self._flat.device))
         return self
 
     def to(self, device):
@@ -190,19 +192,27 @@ class _Base(nn.Module):
             self._job = Job(self.spec, tables, combine=combine, state=_Base.state_dict(self), lr=self._lr,
                             kl_weight=self._kl_weight, loss_cap=1,
                             single_bypass=getattr(self, "_single_bypass", self.spec.kind != "endtoend"))
-            self._job.params = self._flat.data          # share storage with the module's parameters
             self._job.enable_exports()
         j = self._job
+        self.layout.nat_to_kernel(self._flat.data, j.params)     # the module's parameters (views, maybe edited) -> kernel layout
+        j.params_changed()
         j.tables = tables
         j.kl_weight = self._kl_weight if kl_w is None else kl_w
         j.ll_weight = getattr(self, "_ll_weight", 1.0) if ll_w == 1.0 else ll_w
         B, Z = int(xes[0].shape[0]), self.spec.latent
+        nt = tables[0].n_tiles
+        if nt > 1 and (flags & (_lib.NM_F_BACKWARD | _lib.NM_F_GRADS)):
+            raise ValueError(f"a train step takes one batch of at most {_lib.NM_BATCH} rows, got {B} "
+                             f"(forward-only calls -- pred_recon, pred_latent, encode, decode -- take any number)")
         if eps is None:
             eps = torch.randn(B, Z, device=self._device)            # torch.randn_like(mu), cVAE.py:1132
-        j.set_eps(eps)
+        # forward-only calls over more than one 256-row tile: tile t runs as step t and reads draw block t
+        e = torch.zeros(nt * _lib.NM_BATCH, Z, dtype=torch.float32, device=self._device)
+        e[:B] = torch.as_tensor(eps, dtype=torch.float32).to(self._device).reshape(B, Z)
+        j.set_eps(e.view(nt, _lib.NM_BATCH, Z))
         j.step = 0
         j.touch()
-        JobSet([j])._launch(0, 1, 1, flags)
+        JobSet([j])._launch(0, 1, nt, flags)
         return j, B
 
     def _publish_grads(self, which: str, g: torch.Tensor):

@@ -45,7 +45,20 @@ constexpr int PW = 128;          // padded feature width held in P/Q
 constexpr int LDP = 136;         // P/Q row pitch (elements): +8 breaks the 256-B bank period
 constexpr int LDX = 72;          // row pitch of a staged 64-column x chunk inside Q
 constexpr int XCH = 64;          // columns per staged x chunk
-constexpr int STAGE_FLOATS = 4352;   // 32 x (128 + 4) or 64 x (64 + 4) fp32
+constexpr int STAGE_FLOATS = 4608;   // S: 18 KiB (an output-chunk blob, a [64][136] bf16 half tile, or overflow + patches)
+constexpr int IMG_ROWS = 128;
+constexpr int IMG_BYTES = IMG_ROWS * LDP * 2;        // 34,816: a [128][136] bf16 weight image = one half of Q
+constexpr int VEC_BYTES = 1024;                      // the fp32 vectors that travel with an image (one DMA piece)
+constexpr int BLOB_BYTES = IMG_BYTES + VEC_BYTES;    // 35,840
+constexpr int XIMG_BYTES = ROWS * LDX * 2;           // 36,864: one 64-column chunk of a 256-row tile of xb
+constexpr int W0IMG_BYTES = 128 * LDX * 2;           // 18,432: the matching chunk of the first encoder layer's weights
+constexpr int OCH = 64;                              // ROI columns per output chunk
+constexpr int OIMG_BYTES = OCH * LDP * 2;            // 17,408: [64][136] rows of decoder_mean_layer
+constexpr int OBLOB_BYTES = 18432;                   // image + bias[64] + logvar_out[64] (fp32), padded to 18 pieces
+constexpr int ACT_BYTES = ROWS * LDP * 2;            // 69,632: a saved activation in LDS layout
+constexpr int PATCH_LD = 20;                         // floats: 16 + 4 (conflict-free 16-byte patch writes)
+constexpr int PATCH_FLOATS = 16 * PATCH_LD;          // one wave's 16 x 16 fp32 transposition patch
+constexpr int SPATCH_OFF = 8192;                     // patches inside S (bytes): above the 4 KiB the second x slot runs into S
 constexpr float SLOPE = 0.01f;   // F.leaky_relu default (cVAE.py:167,203)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
@@ -72,7 +85,8 @@ struct Ctx {
   const nm_job_t* job;
   __bf16* P;
   __bf16* Q;
-  float* stage;      // [STAGE_FLOATS] gradient slab
+  float* stage;      // [STAGE_FLOATS] S
+  float* vec;        // [2][256] fp32 vector slots (biases / logvar_out that travel with a weight image)
   float* red;        // [64] reduction scratch
   float* colacc;     // [128] per-column accumulators
   float* rowacc;     // [256] per-row accumulators
@@ -90,7 +104,6 @@ struct Ctx {
 
 __host__ __device__ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int wpad(int n) { return rup(n + 1, 32); }   // width incl. the ones column
-__host__ __device__ inline int kpitch(int K) { return rup(K, 8); }      // row pitch of a weight matrix in the flat buffer
 
 // ---- workspace layout (shared by host and device) ------------------------------------------
 struct WsLayout {
@@ -108,7 +121,7 @@ __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
   w.lv_j = o; o += lat;
   w.es = o; o += lat;
   w.dz = o; o += lat;
-  int64_t act = (int64_t)ROWS * PW * 2;
+  int64_t act = (int64_t)ROWS * LDP * 2;       // activation images (LDS layout, reloaded by LDS-DMA)
   w.enc_act = o; o += act * M * L;
   w.dec_act = o; o += act * L;
   w.zc = o; o += act;
@@ -166,10 +179,9 @@ __device__ __forceinline__ GAS T* asg(T* p) {
   return (GAS T*)p;
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every global
-// load/store in flight (weight / p-m-v / x prefetches, activation saves) would be waited for at every
-// phase boundary.  Used wherever the barrier protects P / Q / the slab; hand-offs through global
-// memory between threads keep __syncthreads().
+// Workgroup barrier that orders LDS traffic only: global loads, stores and LDS-DMA copies in flight stay in
+// flight across it (a __syncthreads() drains vmcnt(0) whenever an LDS-DMA is pending).  Used wherever the barrier
+// protects P / Q / S; hand-offs through GLOBAL memory between threads use handoff_barrier().
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -238,28 +250,34 @@ __device__ __forceinline__ bf16x8 lds_frag_tr_scalar(const __bf16* buf, int ld, 
   return r;
 }
 
-// Weight matrices live in the flat parameter buffer as [N][kpitch(K)] fp32 (rows padded to a
-// multiple of 8 with zeros, every row 32-byte aligned), so a fragment is always two 16-byte loads.
-// Forward weight fragment: W[n][k0 .. k0+7] -> bf16x8, zero outside.
+// Weight matrices live in the flat parameter buffer as 16 x 16 fp32 tiles, [ceil(N/16)][ceil(K/16)][16][16], zero
+// padded: 1 KiB per tile.  The trunk touches them only in the Adam sweep (one lane-linear 16-byte access per lane and
+// tile); the head kernels also read their GEMM fragments from them.
+__host__ __device__ inline int ktiles(int K) { return (K + 15) >> 4; }
+__host__ __device__ inline int64_t wt_elems(int N, int K) { return (int64_t)((N + 15) >> 4) * ktiles(K) * 256; }
+__host__ __device__ inline int64_t wt_off(int n, int k, int KT) {
+  return ((int64_t)((n >> 4) * KT + (k >> 4)) << 8) + ((n & 15) << 4) + (k & 15);
+}
+// Forward weight fragment: W[n][k0 .. k0+7] -> bf16x8 (k0 a multiple of 8), zero outside.
 __device__ __forceinline__ bf16x8 w_frag(gcf32 W, int N, int K, int n, int k0) {
-  const int Kp = kpitch(K);
-  const GAS f32x4* p = (const GAS f32x4*)(W + (int64_t)min(n, N - 1) * Kp + min(k0, Kp - 8));
+  const int KT = ktiles(K);
+  const GAS f32x4* p = (const GAS f32x4*)(W + wt_off(min(n, N - 1), min(k0, KT * 16 - 8), KT));
   f32x4 a = p[0], b = p[1];
-  const bool ok = (n < N) && (k0 < Kp);            // pad columns are zeros in memory
+  const bool ok = (n < N) && (k0 < KT * 16);       // pad columns are zeros in memory
   bf16x8 r;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { r[j] = (__bf16)(ok ? a[j] : 0.f); r[4 + j] = (__bf16)(ok ? b[j] : 0.f); }
   return r;
 }
 
-// Dgrad weight fragment: W[n0 + j][k] for j = 0..7 (contraction over the OUTPUT index n).
+// Dgrad weight fragment: W[n0 + j][k] for j = 0..7 (contraction over the OUTPUT index n; n0 a multiple of 8).
 __device__ __forceinline__ bf16x8 w_frag_t(gcf32 W, int N, int K, int n0, int k) {
-  const int Kp = kpitch(K);
+  const int KT = ktiles(K), NP = rup(N, 16);
   bf16x8 r;
-  const int kc = min(k, Kp - 1);
+  const int kc = min(k, KT * 16 - 1);
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)min(n0 + j, N - 1) * Kp + kc];
+  for (int j = 0; j < 8; ++j) v[j] = W[wt_off(min(n0 + j, NP - 1), kc, KT)];
 #pragma unroll
   for (int j = 0; j < 8; ++j) r[j] = (__bf16)((n0 + j < N && k < K) ? v[j] : 0.f);
   return r;
@@ -269,9 +287,9 @@ __device__ __forceinline__ bf16x8 w_frag_t(gcf32 W, int N, int K, int n0, int k)
 __device__ __forceinline__ float block_sum(const Ctx& c, float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
+  lds_barrier();
   if (c.lane == 0) c.red[c.wave] = v;
-  __syncthreads();
+  lds_barrier();
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < NWAVES; ++w) s += c.red[w];
@@ -311,7 +329,8 @@ __device__ __forceinline__ void adam1(const AdamK& a, float g, float& p, float& 
 }
 
 // scalar gradient sink (a handful of elements per step: alpha, d logvar_out)
-__device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g) {
+// (sh: fp32 copy of the element inside a shadow image's vector piece, or nullptr)
+__device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g, GAS float* sh = nullptr) {
   const nm_job_t* J = c.job;
   if (c.flags & NM_F_GRADS) asg(J->grads)[idx] = g;
   if (c.flags & NM_F_ADAM) {
@@ -319,11 +338,96 @@ __device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g) {
     float p = P_[idx], m = M_[idx], v = V_[idx];
     adam1(adam_consts(c), g, p, m, v);
     P_[idx] = p; M_[idx] = m; V_[idx] = v;
+    if (sh) *sh = p;
   }
 }
 
+// ---- LDS-DMA ---------------------------------------------------------------------------------------
+// global_load_lds_dwordx4: every lane moves 16 bytes from its own global address to LDS at (wave-uniform base +
+// lane * 16) -- one wave instruction lands 1 KiB of contiguous LDS, no VGPR in between, tracked by vmcnt like any
+// other vector-memory operation.  Everything the forward and dgrad GEMMs stage (weight images, x chunks, saved
+// activations) is therefore kept in global memory in exactly the LDS layout, in 1-KiB pieces, and is requested
+// one phase ahead of its use.
+typedef __attribute__((address_space(3))) void* lds_vp;
+#ifndef NM_NT_STREAM
+#define NM_NT_STREAM 0
+#endif
+// POL = 2: streaming (nt) -- for bytes this workgroup alone reads, once per step (weight images, saved activations);
+// the ROI tables, which the models of a fold share through L2 / Infinity Cache, keep the default policy.
+template <int POL = 0>
+__device__ __forceinline__ void dma16(const GAS char* src_lane, char* dst_wave) {
+  __builtin_amdgcn_global_load_lds((const GAS void*)src_lane, (lds_vp)dst_wave, 16, 0, POL);
+}
+// pieces [0, npieces) of 1 KiB, contiguous on both sides; wave w takes w, w + 8, ...  Returns the number of
+// instructions THIS wave issued (wave-uniform): the count a later s_waitcnt vmcnt(N) needs.
+template <int POL = (NM_NT_STREAM ? 2 : 0)>
+__device__ __forceinline__ int dma_lin(const Ctx& c, const GAS char* src, char* dst, int npieces) {
+  int n = 0;
+  for (int p = c.wave; p < npieces; p += NWAVES) {
+    dma16<POL>(src + (p << 10) + (c.lane << 4), dst + (p << 10));
+    ++n;
+  }
+  return n;
+}
+// s_waitcnt vmcnt(n): returns once at most n of this wave's vector-memory operations are outstanding, i.e. once
+// everything issued BEFORE the youngest n has completed.  n is wave-uniform; a smaller n than necessary only waits
+// longer.
+__device__ __forceinline__ void wait_vm(int n) {
+  if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (n <= 9) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n <= 11) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n <= 13) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+}
+// Barrier for hand-offs that go through GLOBAL memory between threads of the workgroup (latent statistics, d z):
+// every wave first drains its own stores, then the workgroup meets.  (One CU's vector L1 is in order for its own
+// wavefronts; the explicit drain makes the hand-off independent of that.)
+__device__ __forceinline__ void handoff_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// What a GEMM phase requests for the phase after it: `np` 1-KiB pieces src -> dst and, optionally, one more piece
+// (the fp32 vectors that travel with a weight image) vsrc -> vdst.
+struct Next {
+  const GAS char* src; char* dst; int np;
+  const GAS char* vsrc; char* vdst;
+};
+__device__ __forceinline__ Next no_next() { return Next{nullptr, nullptr, 0, nullptr, nullptr}; }
+__device__ __forceinline__ int issue_next(const Ctx& c, const Next& nx) {
+  int n = 0;
+  if (nx.src) n = dma_lin(c, nx.src, nx.dst, nx.np);
+  if (nx.vsrc && c.wave == 2) { dma16<(NM_NT_STREAM ? 2 : 0)>(nx.vsrc + (c.lane << 4), nx.vdst); ++n; }
+  return n;
+}
+// a [128][136] weight image + its vector piece into half `half` of Q / vector slot `half`
+__device__ __forceinline__ Next blob_to_half(const Ctx& c, const GAS char* blob, int half) {
+  return Next{blob, reinterpret_cast<char*>(c.Q) + half * IMG_BYTES, IMG_BYTES >> 10, blob + IMG_BYTES,
+              reinterpret_cast<char*>(c.vec) + half * VEC_BYTES};
+}
+
 // ---- cooperative copies ----------------------------------------------------------------------
-// global bf16 [256][PW] (saved activation) <-> LDS [256][LDP]; only the first `width` columns move
+// LDS tile [256][LDP] -> global activation image (same layout; the pad piece of every row is skipped)
+__device__ __forceinline__ void store_act_img(const Ctx& c, gbf16 dst, const __bf16* src) {
+#pragma unroll
+  for (int i = 0; i < (ROWS * 16) / WG; ++i) {
+    const int p = c.tid + i * WG, row = p >> 4, seg = p & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * LDP + seg * 8);
+#if NM_NT_STREAM
+    __builtin_nontemporal_store(v, (GAS u32x4*)(dst + row * LDP + seg * 8));
+#else
+    *(GAS u32x4*)(dst + row * LDP + seg * 8) = v;
+#endif
+  }
+}
+// legacy [256][PW] workspace tiles (head kernels, fusion-backward hand-off)
 __device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src, int width) {
   const int segs = width >> 3;                   // 16-byte pieces per row (width is a multiple of 32)
   const float rs = 1.0f / (float)segs;
@@ -345,54 +449,28 @@ __device__ __forceinline__ void store_act(const Ctx& c, gbf16 dst, const __bf16*
   }
 }
 
-// one 64-column chunk of the packed table xb into registers / into Q (pitch LDX)
-constexpr int XPIECES = (ROWS * XCH / 8) / WG;     // 16-byte pieces of an x chunk per thread
-struct XStage { u32x4 v[XPIECES]; };
-__device__ __forceinline__ void xchunk_load(const Ctx& c, XStage& s, const GAS uint16_t* xb, int Kx, int kc) {
-#pragma unroll
-  for (int i = 0; i < XPIECES; ++i) {
-    int p = c.tid + i * WG;            // 2048 pieces of 16 B
-    int row = p >> 3, seg = p & 7;
-    int col = kc * XCH + seg * 8;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    u32x4 ld = *(const GAS u32x4*)(xb + (int64_t)(c.row0 + row) * Kx + min(col, Kx - 8));
-    s.v[i] = (col < Kx) ? ld : z;
-  }
-}
-__device__ __forceinline__ void xchunk_store(const Ctx& c, const XStage& s, __bf16* Q) {
-#pragma unroll
-  for (int i = 0; i < XPIECES; ++i) {
-    int p = c.tid + i * WG;
-    int row = p >> 3, seg = p & 7;
-    *reinterpret_cast<u32x4*>(Q + row * LDX + seg * 8) = s.v[i];
-  }
-}
-
-// ---- LDS-staged weight tiles ---------------------------------------------------------------------
-// A block of up to 128 weight rows is contiguous in the flat buffer (row pitch = kpitch(K)), so the workgroup
-// copies it with coalesced 16-byte loads, converts to bf16 and lays it out [rows][ld] in LDS; the MFMA
-// A-fragments are then ds_read_b128 like the activations (dgrad: the transposing read).  Thread -> (row, piece)
-// is a shift and a mask (32 pieces of 4 floats per row; lanes past the row end idle), no division.
-// A [NR][128] block of a weight matrix with row pitch Kp (rows row0.., columns col0.. of the chunk walk): 32
-// 16-byte pieces per row = 512 contiguous bytes per row; bf16 [NR][ld] in LDS, zeros past the matrix (rows >= N,
-// columns >= Kp).  NR = 128 (8 pieces per thread) or 64 (4).
+// ---- register-staged fp32 weight blocks (head kernels only: the trunk reads bf16 shadow images) -----------------
+// A [NR][128] block of a tiled fp32 weight matrix (rows row0.., columns col0..): 32 pieces of 4 floats per row;
+// bf16 [NR][ld] in LDS, zeros past the matrix.
 template <int NR>
 struct WBlk { f32x4 v[(NR * 128 / 4) / WG]; };
 template <int NR>
-__device__ __forceinline__ void wblk_load(const Ctx& c, WBlk<NR>& s, gcf32 W, int N, int Kp, int row0, int col0) {
+__device__ __forceinline__ void wblk_load(const Ctx& c, WBlk<NR>& s, gcf32 W, int N, int K, int row0, int col0) {
+  const int KT = ktiles(K), NP = rup(N, 16);
 #pragma unroll
   for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
     const int p = c.tid + j * WG, row = row0 + (p >> 5), col = col0 + (p & 31) * 4;
-    s.v[j] = *(const GAS f32x4*)(W + (int64_t)min(row, N - 1) * Kp + min(col, Kp - 4));
+    s.v[j] = *(const GAS f32x4*)(W + wt_off(min(row, NP - 1), min(col, KT * 16 - 4), KT));
   }
 }
 template <int NR>
-__device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf16* dst, int ld, int N, int Kp, int row0,
+__device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf16* dst, int ld, int N, int K, int row0,
                                            int col0) {
+  const int KT = ktiles(K);
 #pragma unroll
   for (int j = 0; j < (NR * 128 / 4) / WG; ++j) {
     const int p = c.tid + j * WG, lr = p >> 5, lc = (p & 31) * 4;
-    const bool ok = row0 + lr < N && col0 + lc < Kp;
+    const bool ok = row0 + lr < N && col0 + lc < KT * 16;       // pad rows / columns inside a tile are zeros in memory
     bf16x4 pk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(ok ? s.v[j][i] : 0.f);
@@ -400,52 +478,25 @@ __device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf
   }
 }
 
-// 64-column chunk kc of the first encoder layer's weights [N][Kp]: 16 pieces of 16 bytes per row, 256
-// contiguous bytes per row; bf16 [128][LDX] in LDS, zeros for rows >= N and columns >= Kp.
-constexpr int W0PIECES = (128 * XCH / 4) / WG;
-struct W0Stage { f32x4 v[W0PIECES]; };
-__device__ __forceinline__ void w0chunk_load(const Ctx& c, W0Stage& s, gcf32 W, int N, int Kp, int kc) {
-#pragma unroll
-  for (int j = 0; j < W0PIECES; ++j) {
-    const int p = c.tid + j * WG, row = p >> 4, col = kc * XCH + (p & 15) * 4;
-    s.v[j] = *(const GAS f32x4*)(W + (int64_t)min(row, N - 1) * Kp + min(col, Kp - 4));
-  }
-}
-__device__ __forceinline__ void w0chunk_store(const Ctx& c, const W0Stage& s, __bf16* dst, int N, int Kp, int kc) {
-#pragma unroll
-  for (int j = 0; j < W0PIECES; ++j) {
-    const int p = c.tid + j * WG, row = p >> 4, col = kc * XCH + (p & 15) * 4;
-    const bool ok = row < N && col < Kp;
-    bf16x4 pk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(ok ? s.v[j][i] : 0.f);
-    *reinterpret_cast<bf16x4*>(dst + row * LDX + (p & 15) * 4) = pk;
-  }
-}
-
-// [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer.  Two branch-free
-// passes (clamped, unconditional loads): the covariate/ones/pad columns from the packed table (its
-// columns D .. D+C hold c | 1), then the z columns from the latent workspace.
+// [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer: the covariate / ones columns from
+// the table's cz block (16-byte pieces, scattered to the unaligned destination with 2-byte LDS stores), zero pad,
+// then the z columns from the latent workspace.
 __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_modality_t& md, gcf32 mu_j, gcf32 es, int Z,
                                          int C, int Zs) {
   const int wz = wpad(Z + C);
   const float rz = 1.0f / (float)Z;
-  const GAS uint16_t* xb = asg(md.xb);
-  // covariates and the ones column: 16-byte pieces of the packed table starting at the aligned column at or
-  // below D (the row pitch Kx is a multiple of 32 and >= D + C + 1, so every piece is inside the row), scattered
-  // into the unaligned destination with 2-byte LDS stores
+  const GAS uint16_t* cz = asg(md.cz);
   {
-    const int c0 = md.D & ~7;
-    const int npc = (md.D + C + 1 - c0 + 7) >> 3;
+    const int npc = (C + 1 + 7) >> 3;
     const float rnp = 1.0f / (float)npc;
     for (int p = c.tid; p < ROWS * npc; p += WG) {
-      const int r = idiv(p, npc, rnp), col0 = c0 + 8 * (p - r * npc);
-      const u32x4 v = *(const GAS u32x4*)(xb + (int64_t)(c.row0 + r) * md.Kx + col0);
+      const int r = idiv(p, npc, rnp), col0 = 8 * (p - r * npc);
+      const u32x4 v = *(const GAS u32x4*)(cz + (int64_t)(c.row0 + r) * md.Cz + col0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = col0 + i - md.D;
+        const int j = col0 + i;
         const uint16_t h = (uint16_t)(v[i >> 1] >> (16 * (i & 1)));
-        if (j >= 0 && j <= C) reinterpret_cast<uint16_t*>(dst)[r * LDP + Z + j] = h;
+        if (j <= C) reinterpret_cast<uint16_t*>(dst)[r * LDP + Z + j] = h;
       }
     }
   }
@@ -486,20 +537,24 @@ __device__ __forceinline__ void bias_acc(const Ctx& c, f32x4 (&acc)[2][RT], gcf3
     for (int rt = 0; rt < RT; ++rt) acc[t][rt] = bv;
   }
 }
-// activation epilogue: P[r][f] = act(acc) for f < N, 1 at f == N (ones column), 0 beyond
-__device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT], int N, int ntn, bool act) {
+// activation epilogue: P[r][f] = act(acc + bias[f]) for f < N, 1 at f == N (ones column), 0 beyond.  bias: LDS
+// vector (zero padded to 128) or nullptr when the accumulators already carry it.
+__device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT], const float* bias, int N, int ntn,
+                                         bool act) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     int ft = c.wn + 4 * t;
     if (ft >= ntn) continue;
     int f0 = ft * 16 + 4 * c.g;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + f0);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       int r = c.wm * WROWS + rt * 16 + c.c16;
       bf16x4 pk;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float v = acc[t][rt][i];
+        float v = acc[t][rt][i] + bv[i];
         v = (f0 + i < N) ? lrelu(v, act) : (f0 + i == N ? 1.0f : 0.0f);
         pk[i] = (__bf16)v;
       }
@@ -509,30 +564,27 @@ __device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT]
 }
 
 // ---- GEMM phase: forward layer, P -> P in place ---------------------------------------------
-// out[r][n] = act(sum_k P[r][k] W[n][k] + b[n]), n < N; column N := 1 (ones column feeding the
-// next layer's bias gradient), columns (N, wpad(N)) := 0.  Optionally saved to `save` (bf16
-// [256][PW]) for the backward pass.
-__device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 b, int N, int K, bool act,
-                                                  gbf16 save) {
+// out[r][n] = act(sum_k P[r][k] W[n][k] + b[n]), n < N; column N := 1 (ones column feeding the next layer's
+// bias gradient), columns (N, wpad(N)) := 0.  The layer's weight image [128][LDP] and bias vector were requested
+// by the PREVIOUS phase into half `half` of Q / vector slot `half`; this phase first requests `nx` (the next
+// phase's image), then waits for its own.  Optionally saved to `save` (activation image) for the backward pass.
+__device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& nx, int N, int K, bool act, gbf16 save) {
   Ctx c = cc;
   relaunder(c);
   const int ksteps = wpad(K) / 32;       // <= 4
   const int ntn = wpad(N) / 16;
-  const int Kp = kpitch(K);
-  // the layer's weights: coalesced global -> registers -> bf16 tile in Q (free during the forward chain)
-  WBlk<128> wsg;
-  wblk_load<128>(c, wsg, W, N, Kp, 0, 0);
-  tr(c, 0);
-  f32x4 acc[2][RT];
-  bias_acc(c, acc, b, N, 0);
-  wblk_store<128>(c, wsg, c.Q, LDP, N, Kp, 0, 0);
+  const __bf16* Wt = c.Q + half * (IMG_ROWS * LDP);
+  const int n_next = issue_next(c, nx);
+  wait_vm(n_next);
   lds_barrier();
+  f32x4 acc[2][RT];
+  zero_acc(acc);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     if (ks < ksteps) {
       bf16x8 wf[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.Q, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+      for (int t = 0; t < 2; ++t) wf[t] = lds_frag(Wt, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
@@ -541,137 +593,116 @@ __device__ __forceinline__ void fwd_layer_inplace(const Ctx& cc, gcf32 W, gcf32 
       }
     }
   }
-  tr(c, 1);
   lds_barrier();                       // every wave has finished reading P
-  tr(c, 2);
-  act_to_P(c, acc, N, ntn, act);
-  tr(c, 3);
+  act_to_P(c, acc, c.vec + half * (VEC_BYTES / 4), N, ntn, act);
   lds_barrier();
-  tr(c, 4);
-  if (save) store_act(c, save, c.P, wpad(N));
-  tr(c, 5);
+  if (save) store_act_img(c, save, c.P);
 }
 
-// ---- GEMM phase: first encoder layer, x streamed through Q in 64-column chunks ----------------
-__device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality_t& md, gcf32 W, gcf32 b, int N, int K,
-                                                bool act, gbf16 save) {
+// ---- GEMM phase: first encoder layer ----------------------------------------------------------
+// x | c | 1 and the layer's weights stream through LDS in 64-column chunks, both as LDS-DMA copies of ready-made
+// images (xb chunk [256][LDX], weight chunk [128][LDX]); two stages (one in P, one in Q: both are dead here), so
+// chunk i + 1 is in flight while chunk i is multiplied.  The last chunk sits in P; `nx` (the next layer's image,
+// into Q) is requested as soon as the Q stage is drained.
+__device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality_t& md, const GAS char* wsh, const Next& nx,
+                                                int N, bool act, gbf16 save) {
   Ctx c = cc;
   relaunder(c);
   const int Kx = md.Kx;
   const int nch = (Kx + XCH - 1) / XCH;
   const int ntn = wpad(N) / 16;
-  const int Kp = kpitch(K);
-  __bf16* Wq = c.Q + ROWS * LDX;          // [128][LDX] weight chunk behind the [256][LDX] x chunk
+  const GAS char* xsrc = (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * nch * XIMG_BYTES;
+  const GAS char* wsrc = wsh + md.enc_s[0];
+  float* bias = c.vec + (VEC_BYTES / 4);            // slot 1 (slot 0 receives nx's vectors)
+  auto stage = [&](int i) { return reinterpret_cast<char*>(((nch - 1 - i) & 1) ? c.Q : c.P); };
+  auto issue_chunk = [&](int i) {
+    char* st = stage(i);
+    int n = dma_lin<0>(c, xsrc + (int64_t)i * XIMG_BYTES, st, XIMG_BYTES >> 10);
+    n += dma_lin(c, wsrc + (int64_t)i * W0IMG_BYTES, st + XIMG_BYTES, W0IMG_BYTES >> 10);
+    return n;
+  };
+  int n_nxt = 0, n_blob = 0;
+  issue_chunk(0);
+  if (c.wave == 3) dma16<(NM_NT_STREAM ? 2 : 0)>(wsrc + (int64_t)nch * W0IMG_BYTES + (c.lane << 4), reinterpret_cast<char*>(bias));
+  if (nch > 1) n_nxt = issue_chunk(1);
+  else n_blob = issue_next(c, nx);
   f32x4 acc[2][RT];
-  bias_acc(c, acc, b, N, 0);
-  XStage st;
-  W0Stage wst;
-  xchunk_load(c, st, asg(md.xb), Kx, 0);
-  w0chunk_load(c, wst, W, N, Kp, 0);
-  tr(c, 6);
-  for (int kc = 0; kc < nch; ++kc) {
-    xchunk_store(c, st, c.Q);
-    w0chunk_store(c, wst, Wq, N, Kp, kc);
-    tr(c, 7);
-    lds_barrier();
-    tr(c, 8);
-    if (kc + 1 < nch) {                   // next chunk's inputs and weights fly during this chunk's MFMAs
-      xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
-      w0chunk_load(c, wst, W, N, Kp, kc + 1);
-    }
-    tr(c, 9);
+  zero_acc(acc);
+  for (int i = 0; i < nch; ++i) {
+    wait_vm(n_nxt + n_blob);
+    lds_barrier();                       // chunk i has landed for every wave
+    const __bf16* X = reinterpret_cast<const __bf16*>(stage(i));
+    const __bf16* Wq = X + ROWS * LDX;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (kc * XCH + ks * 32 < Kx) {
+      if (i * XCH + ks * 32 < Kx) {
         bf16x8 wf[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) wf[t] = lds_frag(Wq, LDX, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          bf16x8 a = lds_frag(c.Q, LDX, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
+          bf16x8 a = lds_frag(X, LDX, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
           for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
         }
       }
     }
-    tr(c, 10);
-    lds_barrier();
-    tr(c, 11);
+    lds_barrier();                       // stage(i) is drained
+    int n_new = 0;
+    if (i + 2 < nch) n_new = issue_chunk(i + 2);
+    else if (i + 2 == nch) n_blob = issue_next(c, nx);        // stage(i) was the Q stage: Q is free from here on
+    n_nxt = n_new;
   }
-  act_to_P(c, acc, N, ntn, act);
+  act_to_P(c, acc, bias, N, ntn, act);
   lds_barrier();
-  if (save) store_act(c, save, c.P, wpad(N));
-  tr(c, 12);
-}
-
-// Both encoder heads as ONE LDS tile [2 Zs][LDP]: rows [0, Z) = enc_mean_layer, rows [Zs, Zs + Z) =
-// enc_logvar_layer, zeros elsewhere (2 Zs <= 128 rows).  Two block copies of up to 64 rows each.
-__device__ __forceinline__ void stage_heads(const Ctx& c, __bf16* dst, gcf32 Wmu, gcf32 Wlv, int Z, int K, int Zs) {
-  const int Kp = kpitch(K);
-  WBlk<64> a, b;
-  wblk_load<64>(c, a, Wmu, Z, Kp, 0, 0);
-  wblk_load<64>(c, b, Wlv, Z, Kp, 0, 0);
-  // a 64-row block covers Zs <= 64 rows of each head; rows >= Z are written as zeros
-  const int rows = Zs;                          // rows of each half actually used
-#pragma unroll
-  for (int j = 0; j < (64 * 128 / 4) / WG; ++j) {
-    const int p = c.tid + j * WG, lr = p >> 5, lc = (p & 31) * 4;
-    if (lr < rows) {
-      const bool ok = lr < Z && lc < Kp;
-      bf16x4 pa, pb;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { pa[i] = (__bf16)(ok ? a.v[j][i] : 0.f); pb[i] = (__bf16)(ok ? b.v[j][i] : 0.f); }
-      *reinterpret_cast<bf16x4*>(dst + lr * LDP + lc) = pa;
-      *reinterpret_cast<bf16x4*>(dst + (Zs + lr) * LDP + lc) = pb;
-    }
-  }
+  if (save) store_act_img(c, save, c.P);
+  tr(c, 0);
 }
 
 // ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
-__device__ __forceinline__ void fwd_heads(const Ctx& cc, gcf32 Wmu, gcf32 bmu, gcf32 Wlv, gcf32 blv, int Z, int K,
-                                          gf32 mu_out, gf32 lv_out, int Zs) {
+// Heads image: rows [0, Z) = enc_mean_layer, rows [Zs, Zs + Z) = enc_logvar_layer, zeros elsewhere; the vector
+// piece holds the biases at the same row indices.
+__device__ __forceinline__ void fwd_heads(const Ctx& cc, int half, const Next& nx, int Z, int K, gf32 mu_out, gf32 lv_out,
+                                          int Zs) {
   Ctx c = cc;
   relaunder(c);
   const int ksteps = wpad(K) / 32;
   const int nzt = Zs / 16;
-  stage_heads(c, c.Q, Wmu, Wlv, Z, K, Zs);          // Q is free during the forward chain
+  const __bf16* Wt = c.Q + half * (IMG_ROWS * LDP);
+  const float* bias = c.vec + half * (VEC_BYTES / 4);
+  const int n_next = issue_next(c, nx);
+  wait_vm(n_next);
   lds_barrier();
   // unit = (feature tile, row tile of the wave's row half): the 4 waves of a row half share them round-robin,
   // so all 8 waves work even when the latent fits one feature tile
   for (int u = c.wn; u < nzt * RT; u += NWN) {
     const int ft = u / RT, rt = u - ft * RT;
     const int f0 = ft * 16 + 4 * c.g;
-    f32x4 am, al;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x0 = bmu[min(f0 + i, Z - 1)], x1 = blv[min(f0 + i, Z - 1)];
-      am[i] = (f0 + i < Z) ? x0 : 0.f;
-      al[i] = (f0 + i < Z) ? x1 : 0.f;
-    }
+    f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = am;
     for (int ks = 0; ks < ksteps; ++ks) {
-      const bf16x8 fm = lds_frag(c.Q, LDP, ft * 16 + c.c16, ks * 32 + 8 * c.g);
-      const bf16x8 fl = lds_frag(c.Q, LDP, Zs + ft * 16 + c.c16, ks * 32 + 8 * c.g);
+      const bf16x8 fm = lds_frag(Wt, LDP, ft * 16 + c.c16, ks * 32 + 8 * c.g);
+      const bf16x8 fl = lds_frag(Wt, LDP, Zs + ft * 16 + c.c16, ks * 32 + 8 * c.g);
       const bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
       am = mfma(fm, a, am);
       al = mfma(fl, a, al);
     }
     const int r = c.wm * WROWS + rt * 16 + c.c16;
-    *(GAS f32x4*)(mu_out + r * Zs + f0) = am;        // features >= Z are exactly 0 (zero weight rows, zero bias)
+    am += *reinterpret_cast<const f32x4*>(bias + f0);            // features >= Z: zero weight rows, zero bias
+    al += *reinterpret_cast<const f32x4*>(bias + Zs + f0);
+    *(GAS f32x4*)(mu_out + r * Zs + f0) = am;
     *(GAS f32x4*)(lv_out + r * Zs + f0) = al;
   }
-  tr(c, 13);
-  __syncthreads();
-  tr(c, 14);
+  lds_barrier();                          // P and the image are drained (the latent hand-off has its own barrier)
+  tr(c, 2);
 }
 
 // ---- dgrad: acc[k][r] += sum_n A[r][n] W[n][k]  (contraction over the columns of A) ------------
 // k tiles {wn, wn+4} of wpad(K); nsteps = 32-wide steps over A's columns; n_base = index of A's
-// column 0 in W's row space.
+// column 0 in W's row space.  Weights straight from the (tiled) fp32 master: head kernels only.
 __device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][RT], const __bf16* A, gcf32 W, int N, int K,
                                           int nsteps, int n_base) {
   Ctx c = cc;
   relaunder(c);
-  tr(c, 33);
   for (int s0 = 0; s0 < nsteps; s0 += 2) {
     bf16x8 wf[2][2];
 #pragma unroll
@@ -694,10 +725,10 @@ __device__ __forceinline__ void dgrad_acc(const Ctx& cc, f32x4 (&acc)[2][RT], co
 }
 
 // dgrad with the weights taken from an LDS tile T[n][k] (bf16, row pitch ld) through the transposing read:
-// lane (c16, g) gets T[s*32 + 8g + j][ktile*16 + c16], j = 0..7 -- the fragment the 8 strided dword loads of
-// w_frag_t assemble from global memory.  A = delta rows in LDS, column n_col0 + s*32 onwards.
-__device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], const __bf16* A, int n_col0, const __bf16* T,
-                                           int ld, int nsteps) {
+// lane (c16, g) gets T[s*32 + 8g + j][ktile*16 + c16], j = 0..7.  A = delta rows in LDS (row pitch lda), column
+// n_col0 + s*32 onwards.
+__device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], const __bf16* A, int lda, int n_col0,
+                                           const __bf16* T, int ld, int nsteps) {
   for (int s = 0; s < nsteps; ++s) {
     bf16x4 l0, h0, l1, h1;
     const unsigned a0 = tr_addr(T, ld, s * 32, (c.wn + 0) * 16, c.lane), a1 = tr_addr(T, ld, s * 32, (c.wn + 4) * 16, c.lane);
@@ -708,24 +739,29 @@ __device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], co
     const bf16x8 wf0 = join4(l0, h0), wf1 = join4(l1, h1);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      bf16x8 a = lds_frag(A, LDP, c.wm * WROWS + rt * 16 + c.c16, n_col0 + s * 32 + 8 * c.g);
+      bf16x8 a = lds_frag(A, lda, c.wm * WROWS + rt * 16 + c.c16, n_col0 + s * 32 + 8 * c.g);
       acc[0][rt] = mfma(wf0, a, acc[0][rt]);
       acc[1][rt] = mfma(wf1, a, acc[1][rt]);
     }
   }
 }
-// Hidden-layer dgrad: stage W[N][K] in Q (coalesced copy, as in the forward pass), then dgrad_tile.  On return
-// the tile is still being read by other waves: the caller puts a barrier before reusing Q.
-__device__ __forceinline__ void dgrad_staged(const Ctx& cc, f32x4 (&acc)[2][RT], const __bf16* A, gcf32 W, int N, int K) {
+// Hidden-layer backward, first half: P = delta of the layer's output [256][N].  The layer's weight image goes to
+// the lower half of Q and, meanwhile, rows 128..255 of the layer's saved INPUT activation to the upper half; after
+// the dgrad the lower 128 rows follow, so that on return Q = input activation (for wgrad and the ReLU mask).
+__device__ __forceinline__ void dgrad_hidden(const Ctx& cc, f32x4 (&acc)[2][RT], const GAS char* w_img, const GAS char* act_img,
+                                             int N) {
   Ctx c = cc;
   relaunder(c);
-  const int Kp = kpitch(K);
-  WBlk<128> wsg;
-  wblk_load<128>(c, wsg, W, N, Kp, 0, 0);
-  tr(c, 33);
-  wblk_store<128>(c, wsg, c.Q, LDP, N, Kp, 0, 0);
+  char* Qb = reinterpret_cast<char*>(c.Q);
+  dma_lin(c, w_img, Qb, IMG_BYTES >> 10);
+  const int n_hi = dma_lin(c, act_img + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
+  wait_vm(n_hi);
   lds_barrier();
-  dgrad_tile(c, acc, A, 0, c.Q, LDP, wpad(N) / 32);
+  dgrad_tile(c, acc, c.P, LDP, 0, c.Q, LDP, wpad(N) / 32);
+  lds_barrier();                              // weight image fully read
+  dma_lin(c, act_img, Qb, IMG_BYTES >> 10);
+  wait_vm(0);
+  lds_barrier();
 }
 
 // P[r][k] = acc[k][r] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
@@ -757,136 +793,174 @@ __device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2
 }
 
 // ---- wgrad + Adam ------------------------------------------------------------------------------
-// dW[n][k] = sum_r A[r][a_col0 + n] * B[r][kk], n in [0,N), B columns kk in [0, ncols) map to the
-// weight column k = k_base + kk; k < K is W[n][k], k == K the bias b[n] (ones column), beyond:
-// nothing.  The output is produced in slabs of SR rows x SC columns (32 x 128 or 64 x 64, = one
-// 16-byte parameter group per thread).  Per slab every thread first ISSUES the loads of its group's
-// p/m/v (so their HBM latency hides under the MFMA work), the 16 waves then write their accumulator
-// tiles (4 consecutive k per lane) into the LDS slab S, and after one barrier every thread applies
-// Adam to its group with 16-byte stores: the sweep walks contiguous parameter memory.
+// dW[n][k] = sum_r A[r][a_col0 + n] * B[r][kk], n in [0,N), B columns kk in [0, ncols) map to the weight column
+// k = k_base + kk (k_base a multiple of 16); k < K is W[n][k], k == K the bias b[n] (ones column), beyond: nothing.
+// A unit = one 16-row n tile x two adjacent 16-column k tiles (the n-side fragment is shared).  The waves take
+// units round-robin and run them INDEPENDENTLY -- no workgroup barrier, no shared slab: per unit a wave
+//   (i)   has already requested p / m / v of its NEXT unit: the master keeps every 16 x 16 tile as 1 KiB of
+//         contiguous memory, so each request is one lane-linear 16-byte load per lane (full lines, streaming);
+//   (ii)  runs the unit's MFMAs through the transposing LDS reads;
+//   (iii) turns each accumulator tile (lane = row n, 4 consecutive k) into the master's lane order through a
+//         private 16 x 16 fp32 LDS patch (the LDS traffic of one wave is in order: no barrier);
+//   (iv)  applies Adam, stores p / m / v lane-linear again and the new weights as bf16 into the shadow image.
+// While one wave waits for its moments the others are in their MFMA loops.  One barrier at the end (the caller
+// may overwrite the operands).
+struct WgT {
+  int64_t w_off;      // master offset of tile (0, 0) of this row block
+  int64_t b_off;      // master offset of the bias of row 0 (< 0: the pass has no bias column)
+  GAS char* sh;       // shadow image of (row 0, pass column 0); nullptr: none
+  int sh_pitch;       // bytes per image row
+  GAS float* sh_b;    // fp32 bias copy that travels with the image (row 0); nullptr: none
+  float* patch;       // LDS, NWAVES * PATCH_FLOATS floats
+};
+struct PMV { f32x4 p[2], m[2], v[2]; float bp, bm, bv; };
+
 template <bool SCALAR_TR>
 __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
-                                           int N, int K, int k_base, int ncols, int64_t w_off, int64_t b_off) {
+                                           int N, int K, int k_base, int ncols, const WgT& T) {
   Ctx c = cc;
   relaunder(c);
   const nm_job_t* J = c.job;
-  const bool wide = ncols > 64;                 // slab shape
-  const int SR = wide ? 32 : 64, SP = (wide ? 128 : 64) + 4;      // slab rows, slab pitch (floats)
-  const int Kp = kpitch(K);
-  const int nkt = (ncols + 15) / 16;            // k tiles in this pass
-  const int gpr = max(0, min(ncols, Kp - k_base)) >> 2;          // 16-byte parameter groups per row in this pass
-  const float rg = gpr > 0 ? 1.0f / (float)gpr : 0.f;
-  const bool has_bias = (b_off >= 0) && (K >= k_base) && (K < k_base + ncols);   // b_off < 0: no bias column in B
+  const int KT = ktiles(K), kt0 = k_base >> 4;
+  const int nnt = (N + 15) >> 4;                // n tiles
+  const int nktp = (ncols + 15) >> 4;           // k tiles of this pass
+  const int nkp = (nktp + 1) >> 1;              // pairs
+  const int nunits = nnt * nkp;
+  const bool has_bias = (T.b_off >= 0) && (K >= k_base) && (K < k_base + ncols);
+  const int kb = K - k_base;                    // pass column of the ones column
+  const int kb_pair = has_bias ? (kb >> 5) : -1, kb_j = (kb >> 4) & 1, kb_col = kb & 15;
   const bool do_adam = (c.flags & NM_F_ADAM) != 0;
+  const bool do_grads = (c.flags & NM_F_GRADS) != 0;
   const AdamK ak = adam_consts(c);
-  constexpr int NG = 1024 / WG;                 // 16-byte parameter groups per thread and slab
-  for (int n0 = 0; n0 < N; n0 += SR) {
-    const int nr = min(SR, N - n0);
-    const int nts = (nr + 15) / 16;
-    // ---- this thread's parameter groups: issue the p/m/v loads now ----
-    bool mine[NG];
-    int qn[NG], qk[NG];
-    int64_t pidx[NG];
-    f32x4 pv[NG], mv[NG], vv[NG];
+  gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
+  float* patch = T.patch + c.wave * PATCH_FLOATS;
+  const int prow = c.lane >> 2, pcol = (c.lane & 3) * 4;          // this lane's element group inside a tile
+
+  auto request = [&](int u, PMV& s) {
+    const int nt = u / nkp, kp = u - nt * nkp;            // wave-uniform: scalar division
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const int q = c.tid + j * WG;
-      mine[j] = q < nr * gpr;
-      qn[j] = mine[j] ? idiv(q, gpr, rg) : 0;
-      qk[j] = mine[j] ? (q - qn[j] * gpr) * 4 : 0;                              // column inside the pass
-      pidx[j] = w_off + (int64_t)(n0 + qn[j]) * Kp + k_base + qk[j];            // 16-byte aligned
-      pv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; mv[j] = pv[j]; vv[j] = pv[j];
-      if (do_adam && mine[j]) {
-        pv[j] = *(const GAS f32x4*)(asg(J->params) + pidx[j]);
-        // the moments are touched once per step: streaming (nt) accesses keep them from evicting the weights
-        // and activations that are re-read within the step (measured: -9 % config A, -2.5 % 3-modality)
-        mv[j] = __builtin_nontemporal_load((const GAS f32x4*)(asg(J->adam_m) + pidx[j]));
-        vv[j] = __builtin_nontemporal_load((const GAS f32x4*)(asg(J->adam_v) + pidx[j]));
+    for (int j = 0; j < 2; ++j) {
+      const int ktl = 2 * kp + j;
+      s.p[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s.m[j] = s.p[j]; s.v[j] = s.p[j];
+      if (ktl < nktp && kt0 + ktl < KT) {
+        const int64_t idx = T.w_off + ((int64_t)(nt * KT + kt0 + ktl) << 8) + c.lane * 4;
+#if NM_NT_STREAM
+        s.p[j] = __builtin_nontemporal_load((const GAS f32x4*)(Pp + idx));
+#else
+        s.p[j] = *(const GAS f32x4*)(Pp + idx);
+#endif
+        // the moments are touched once per step: streaming (nt) accesses keep them from evicting what is re-read
+        s.m[j] = __builtin_nontemporal_load((const GAS f32x4*)(Mp + idx));
+        s.v[j] = __builtin_nontemporal_load((const GAS f32x4*)(Vp + idx));
       }
     }
-    // bias element of this thread (first nr threads): its p/m/v fly with the slab's groups
-    const bool bmine = has_bias && c.tid < nr;
-    const int64_t bidx = b_off + n0 + (bmine ? c.tid : 0);
-    float bp = 0.f, bm = 0.f, bv = 0.f;
-    if (do_adam && bmine) { bp = asg(J->params)[bidx]; bm = asg(J->adam_m)[bidx]; bv = asg(J->adam_v)[bidx]; }
-    tr(c, 26);
-    // ---- tiles -> slab: a unit is one k tile x two n tiles (the k-side fragment is shared) ----
-    const int npairs = (nts + 1) / 2;
-    for (int u = c.wave; u < nkt * npairs; u += NWAVES) {
-      const int kt = u % nkt, np = u / nkt;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-      const int ncol0 = a_col0 + n0 + np * 32;
-      if (SCALAR_TR) {
-        for (int rs = 0; rs < ROWS / 32; ++rs) {
-          bf16x8 akf = lds_frag_tr_scalar(B, ldb, rs * 32, kt * 16, c.lane);
-          acc0 = mfma(akf, lds_frag_tr_scalar(A, lda, rs * 32, ncol0, c.lane), acc0);
-          acc1 = mfma(akf, lds_frag_tr_scalar(A, lda, rs * 32, ncol0 + 16, c.lane), acc1);
-        }
-      } else {
-        unsigned na = tr_addr_il(A, lda, 0, ncol0, c.lane);
-        unsigned ka = tr_addr_il(B, ldb, 0, kt * 16, c.lane);
-        const unsigned n_step = 32u * lda * 2u, k_step = 32u * ldb * 2u;
-        const unsigned n4 = 1u * lda * 2u, k4 = 1u * ldb * 2u;         // second read of a pair: the odd rows
+    s.bp = 0.f; s.bm = 0.f; s.bv = 0.f;
+    if (kp == kb_pair) {
+      const int64_t bidx = T.b_off + min(nt * 16 + prow, N - 1);
+      s.bp = Pp[bidx]; s.bm = Mp[bidx]; s.bv = Vp[bidx];
+    }
+  };
+
+  PMV cur, nxt;
+  int u = c.wave;
+  if (do_adam && u < nunits) request(u, cur);
+  while (u < nunits) {
+    const int un = u + NWAVES;
+    if (do_adam && un < nunits) request(un, nxt);
+    const int nt = u / nkp, kp = u - nt * nkp;
+    // ---- MFMAs: acc[j] = k tile 2 kp + j of n tile nt ----
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int ncol0 = a_col0 + nt * 16;
+    if (SCALAR_TR) {
+      for (int rs = 0; rs < ROWS / 32; ++rs) {
+        bf16x8 nf = lds_frag_tr_scalar(A, lda, rs * 32, ncol0, c.lane);
+        acc[0] = mfma(lds_frag_tr_scalar(B, ldb, rs * 32, kp * 32, c.lane), nf, acc[0]);
+        acc[1] = mfma(lds_frag_tr_scalar(B, ldb, rs * 32, kp * 32 + 16, c.lane), nf, acc[1]);
+      }
+    } else {
+      unsigned na = tr_addr_il(A, lda, 0, ncol0, c.lane);
+      unsigned ka = tr_addr_il(B, ldb, 0, kp * 32, c.lane);
+      const unsigned n_step = 32u * lda * 2u, k_step = 32u * ldb * 2u;
+      const unsigned n4 = 1u * lda * 2u, k4 = 1u * ldb * 2u;         // second read of a pair: the odd rows
 #pragma unroll 2
-        for (int rs = 0; rs < ROWS / 32; rs += 2) {
-          // two row steps per wait: 12 transposing reads in flight (k side once, two n tiles)
-          bf16x4 k0v, k1v, k2v, k3v, a0, a1, a2, a3, b0, b1, b2, b3;
-          unsigned na1 = na + n4, ka1 = ka + k4, na2 = na + n_step, ka2 = ka + k_step;
-          unsigned na3 = na2 + n4, ka3 = ka2 + k4;
-          NM_TR_READ(k0v, ka, 0);  NM_TR_READ(k1v, ka1, 0);
-          NM_TR_READ(a0, na, 0);   NM_TR_READ(a1, na1, 0);
-          NM_TR_READ(b0, na, 32);  NM_TR_READ(b1, na1, 32);
-          NM_TR_READ(k2v, ka2, 0); NM_TR_READ(k3v, ka3, 0);
-          NM_TR_READ(a2, na2, 0);  NM_TR_READ(a3, na3, 0);
-          NM_TR_READ(b2, na2, 32); NM_TR_READ(b3, na3, 32);
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(k0v), "+v"(k1v), "+v"(k2v), "+v"(k3v), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0),
-                         "+v"(b1), "+v"(b2), "+v"(b3));
-          bf16x8 kf0 = join4(k0v, k1v), kf1 = join4(k2v, k3v);
-          acc0 = mfma(kf0, join4(a0, a1), acc0);
-          acc1 = mfma(kf0, join4(b0, b1), acc1);
-          acc0 = mfma(kf1, join4(a2, a3), acc0);
-          acc1 = mfma(kf1, join4(b2, b3), acc1);
-          na += 2 * n_step; ka += 2 * k_step;
-        }
+      for (int rs = 0; rs < ROWS / 32; rs += 2) {
+        // two row steps per wait: 12 transposing reads in flight (n side once, two k tiles)
+        bf16x4 n0v, n1v, n2v, n3v, a0, a1, a2, a3, b0, b1, b2, b3;
+        unsigned na1 = na + n4, ka1 = ka + k4, na2 = na + n_step, ka2 = ka + k_step;
+        unsigned na3 = na2 + n4, ka3 = ka2 + k4;
+        NM_TR_READ(n0v, na, 0);  NM_TR_READ(n1v, na1, 0);
+        NM_TR_READ(a0, ka, 0);   NM_TR_READ(a1, ka1, 0);
+        NM_TR_READ(b0, ka, 32);  NM_TR_READ(b1, ka1, 32);
+        NM_TR_READ(n2v, na2, 0); NM_TR_READ(n3v, na3, 0);
+        NM_TR_READ(a2, ka2, 0);  NM_TR_READ(a3, ka3, 0);
+        NM_TR_READ(b2, ka2, 32); NM_TR_READ(b3, ka3, 32);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(n0v), "+v"(n1v), "+v"(n2v), "+v"(n3v), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0),
+                       "+v"(b1), "+v"(b2), "+v"(b3));
+        bf16x8 nf0 = join4(n0v, n1v), nf1 = join4(n2v, n3v);
+        acc[0] = mfma(join4(a0, a1), nf0, acc[0]);
+        acc[1] = mfma(join4(b0, b1), nf0, acc[1]);
+        acc[0] = mfma(join4(a2, a3), nf1, acc[0]);
+        acc[1] = mfma(join4(b2, b3), nf1, acc[1]);
+        na += 2 * n_step; ka += 2 * k_step;
       }
-      // lane holds dW[n = (2 np + h)*16 + c16][kk = kt*16 + 4g .. +3]
-      *reinterpret_cast<f32x4*>(c.stage + (np * 32 + c.c16) * SP + kt * 16 + 4 * c.g) = acc0;
-      if (np * 2 + 1 < nts) *reinterpret_cast<f32x4*>(c.stage + (np * 32 + 16 + c.c16) * SP + kt * 16 + 4 * c.g) = acc1;
     }
-    tr(c, 27);
-    lds_barrier();
-    tr(c, 28);
-    // ---- Adam on this thread's group; bias column by the first nr threads ----
+    // ---- per tile: accumulators -> master lane order -> Adam ----
+    // MFMA lane (c16, g) holds dW[n = nt*16 + c16][kk = ktl*16 + 4g .. +3]; master lane L holds row L / 4,
+    // columns 4 (L % 4) .. +3 of the tile.
+    const int n = nt * 16 + prow;
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      if (mine[j]) {
-        f32x4 g = *reinterpret_cast<const f32x4*>(c.stage + qn[j] * SP + qk[j]);
+    for (int j = 0; j < 2; ++j) {
+      const int ktl = 2 * kp + j;
+      *reinterpret_cast<f32x4*>(patch + c.c16 * PATCH_LD + 4 * c.g) = acc[j];
+      f32x4 g = *reinterpret_cast<const f32x4*>(patch + prow * PATCH_LD + pcol);
+      const float bg = patch[prow * PATCH_LD + kb_col];
+      const int k0 = k_base + ktl * 16 + pcol;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = (k_base + qk[j] + i < K) ? g[i] : 0.f;      // pad columns keep zero gradient
-        if (c.flags & NM_F_GRADS) *(GAS f32x4*)(asg(J->grads) + pidx[j]) = g;
+      for (int i = 0; i < 4; ++i) g[i] = (n < N && k0 + i < K) ? g[i] : 0.f;          // pad rows / columns keep zero gradient
+      if (ktl < nktp && kt0 + ktl < KT) {                                            // wave-uniform
+        const int64_t idx = T.w_off + ((int64_t)(nt * KT + kt0 + ktl) << 8) + c.lane * 4;
+        if (do_grads) *(GAS f32x4*)(asg(J->grads) + idx) = g;
         if (do_adam) {
-          f32x4 p4 = pv[j], m4 = mv[j], v4 = vv[j];
+          f32x4 p4 = cur.p[j], m4 = cur.m[j], v4 = cur.v[j];
 #pragma unroll
           for (int i = 0; i < 4; ++i) { float pp = p4[i], mm = m4[i], v2 = v4[i]; adam1(ak, g[i], pp, mm, v2); p4[i] = pp; m4[i] = mm; v4[i] = v2; }
-          *(GAS f32x4*)(asg(J->params) + pidx[j]) = p4;
-          __builtin_nontemporal_store(m4, (GAS f32x4*)(asg(J->adam_m) + pidx[j]));
-          __builtin_nontemporal_store(v4, (GAS f32x4*)(asg(J->adam_v) + pidx[j]));
+#if NM_NT_STREAM
+          __builtin_nontemporal_store(p4, (GAS f32x4*)(Pp + idx));
+#else
+          *(GAS f32x4*)(Pp + idx) = p4;
+#endif
+          __builtin_nontemporal_store(m4, (GAS f32x4*)(Mp + idx));
+          __builtin_nontemporal_store(v4, (GAS f32x4*)(Vp + idx));
+          if (T.sh) {
+            bf16x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[i] = (__bf16)p4[i];
+#if NM_NT_STREAM
+            __builtin_nontemporal_store(pk, (GAS bf16x4*)(T.sh + (int64_t)n * T.sh_pitch + (ktl * 16 + pcol) * 2));
+#else
+            *(GAS bf16x4*)(T.sh + (int64_t)n * T.sh_pitch + (ktl * 16 + pcol) * 2) = pk;
+#endif
+          }
+        }
+      }
+      if (kp == kb_pair && j == kb_j) {              // wave-uniform: this tile carries the ones column
+        if (pcol == 0 && n < N) {                    // one lane per row
+          const int64_t bidx = T.b_off + n;
+          if (do_grads) asg(J->grads)[bidx] = bg;
+          if (do_adam) {
+            float bp = cur.bp, bm = cur.bm, bv = cur.bv;
+            adam1(ak, bg, bp, bm, bv);
+            Pp[bidx] = bp; Mp[bidx] = bm; Vp[bidx] = bv;
+            if (T.sh_b) T.sh_b[n] = bp;
+          }
         }
       }
     }
-    if (bmine) {
-      const float bg = c.stage[c.tid * SP + (K - k_base)];
-      if (c.flags & NM_F_GRADS) asg(J->grads)[bidx] = bg;
-      if (do_adam) {
-        adam1(ak, bg, bp, bm, bv);
-        asg(J->params)[bidx] = bp; asg(J->adam_m)[bidx] = bm; asg(J->adam_v)[bidx] = bv;
-      }
-    }
-    tr(c, 29);
-    lds_barrier();
-    tr(c, 30);
+    cur = nxt;
+    u = un;
   }
+  lds_barrier();                                    // every wave has finished reading A / B
 }
 
 // ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
@@ -1009,29 +1083,40 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   gf32 ws_lv_j = (gf32)(c.ws + wl.lv_j);
   gf32 ws_es = (gf32)(c.ws + wl.es);
   gf32 ws_dz = (gf32)(c.ws + wl.dz);
-  gbf16 ws_enc = (gbf16)(c.ws + wl.enc_act);
-  gbf16 ws_dec = (gbf16)(c.ws + wl.dec_act);
-  gbf16 ws_zc = (gbf16)(c.ws + wl.zc);
-  gcf32 prm = asg(J->params);
+  GAS char* ws_enc = c.ws + wl.enc_act;         // activation images [256][LDP], ACT_BYTES each
+  GAS char* ws_dec = c.ws + wl.dec_act;
+  GAS char* ws_zc = c.ws + wl.zc;
+  GAS char* wsh = (GAS char*)J->wsh;
+  char* const Sb = reinterpret_cast<char*>(c.stage);
+  char* const Qb = reinterpret_cast<char*>(c.Q);
+  char* const Pb = reinterpret_cast<char*>(c.P);
 
   // ================= encoders =================
   for (int m = 0; m < Me; ++m) {
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
-    gbf16 save0 = bwd ? ws_enc + (int64_t)(m * L + 0) * ROWS * PW : (gbf16)nullptr;
-    fwd_first_layer(c, md, prm + md.enc_w[0], prm + md.enc_b[0], J->H[0], md.D + C, nl, save0);
+    gbf16 save0 = bwd ? (gbf16)(ws_enc + (int64_t)(m * L + 0) * ACT_BYTES) : (gbf16)nullptr;
+    // the image of the phase after the first layer goes to the lower half of Q
+    const GAS char* after0 = wsh + (L > 1 ? md.enc_s[1] : md.heads_s);
+    fwd_first_layer(c, md, wsh, blob_to_half(c, after0, 0), J->H[0], nl, save0);
     prof(c, PH_ENC_L0);
+    int half = 0;
     for (int e = 1; e < L; ++e) {
-      gbf16 sv = bwd ? ws_enc + (int64_t)(m * L + e) * ROWS * PW : (gbf16)nullptr;
-      fwd_layer_inplace(c, prm + md.enc_w[e], prm + md.enc_b[e], J->H[e], J->H[e - 1], nl, sv);
+      gbf16 sv = bwd ? (gbf16)(ws_enc + (int64_t)(m * L + e) * ACT_BYTES) : (gbf16)nullptr;
+      const GAS char* nxt = wsh + (e + 1 < L ? md.enc_s[e + 1] : md.heads_s);
+      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1), J->H[e], J->H[e - 1], nl, sv);
+      half ^= 1;
     }
+    tr(c, 1);
     prof(c, PH_ENC_REST);
-    fwd_heads(c, prm + md.mu_w, prm + md.mu_b, prm + md.lv_w, prm + md.lv_b, Z, J->H[L - 1],
-              ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs);
+    fwd_heads(c, half, no_next(), Z, J->H[L - 1], ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs);
     prof(c, PH_HEADS);
   }
 
   // ================= fusion + reparameterisation + KL =================
+  handoff_barrier();                             // the heads' mu / logvar stores are complete
+  // first decoder layer's image: requested now, lands during the latent arithmetic
+  issue_next(c, blob_to_half(c, wsh + J->mod[0].dec_s[0], 0));
   float al[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
   if (J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass)) softmax_alpha(J, al);
   auto load_lat = [&](Lat& Lt, int r, int z) {
@@ -1068,9 +1153,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       }
     }
   }
-  tr(c, 15);
   float kl = block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
-  tr(c, 22);
+  handoff_barrier();                                   // mu_j / es are complete for build_zc
+  tr(c, 3);
   prof(c, PH_LATENT);
 
   // ================= decoders (forward, NLL, and the whole decoder backward) =================
@@ -1080,220 +1165,191 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const nm_modality_t& md = J->mod[m];
     const int D = md.D;
     const int Kd0 = Z + C;
+    if (m > 0) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
     // z | c | 1: built by the first decoder; the others reuse it when all tables carry the same covariates
     const bool reuse_zc = J->shared_cov && M > 1;
     if (m == 0 || !reuse_zc) {
       build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
-      tr(c, 23);
       lds_barrier();
-      if (bwd || reuse_zc) store_act(c, ws_zc, c.P, wpad(Kd0));
+      if (bwd || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P);
     } else {
-      __syncthreads();                             // the first decoder's copy is complete in memory
-      load_act(c, c.P, ws_zc, wpad(Kd0));
-      tr(c, 23);
-      lds_barrier();
+      dma_lin(c, ws_zc, Pb, ACT_BYTES >> 10);          // waited for by the first layer (it waits for everything older)
     }
-    tr(c, 24);
+    tr(c, 4);
     prof(c, PH_DEC_ZC);
-    // --- hidden decoder layers ---
+    // --- hidden decoder layers; the last one requests output chunk 0 into slot B (= S) ---
+    const int nck = (D + OCH - 1) / OCH;
+    const GAS char* oblob = wsh + md.out_s;
+    int half = 0;
     for (int d = 0; d < L; ++d) {
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
-      gbf16 sv = (bwd && d < L - 1) ? ws_dec + (int64_t)d * ROWS * PW : (gbf16)nullptr;
-      fwd_layer_inplace(c, prm + md.dec_w[d], prm + md.dec_b[d], Nout, Kin, nl, sv);
+      gbf16 sv = (bwd && d < L - 1) ? (gbf16)(ws_dec + (int64_t)d * ACT_BYTES) : (gbf16)nullptr;
+      Next nx = (d + 1 < L) ? blob_to_half(c, wsh + md.dec_s[d + 1], half ^ 1)
+                            : Next{oblob, Sb, OBLOB_BYTES >> 10, nullptr, nullptr};
+      fwd_layer(c, half, nx, Nout, Kin, nl, sv);
+      half ^= 1;
     }
+    tr(c, 5);
     prof(c, PH_DEC_HID);
-    // --- output layer in chunks of 128 ROI columns, fused with NLL, its backward and Adam ---
+    // --- output layer in chunks of 64 ROI columns, fused with NLL, its backward and Adam ---
+    // LDS during the chunk loop: P = last hidden activation; Q = [delta chunk [256][LDX] | slot A | patches];
+    // S = slot B.  Chunk ch's blob ([64][LDP] weight rows, bias[64], logvar_out[64]) sits in slot B for even ch,
+    // slot A for odd ch; the other slot receives chunk ch + 1 while chunk ch is processed.
     const int Hl = J->H[0];                       // width feeding the output layer
-    gcf32 Wo = prm + md.out_w;
-    gcf32 bo = prm + md.out_b;
-    gcf32 lvo = prm + md.logvar_out;
+    const int KTo = ktiles(Hl);
     gcf32 xf = asg(md.x_f32);
     const int xp = md.x_pitch;
+    __bf16* const Dq = c.Q;                       // delta chunk, row pitch LDX
+    char* const slotA = Qb + XIMG_BYTES;
+    float* const opatch = reinterpret_cast<float*>(Qb + XIMG_BYTES + OBLOB_BYTES);
     f32x4 accg[2][RT];
     zero_acc(accg);
     float nll_part = 0.f;
     if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
-    const int nchunks = (D + PW - 1) / PW;
     // read once, outside the per-lane selects below: a descriptor load inside `cond ? load * x : 0` becomes a
     // lane-divergent branch, and register spills placed around such branches are not safe with this compiler
     // (tools/check_spill_exec.py)
     const float llw_b = J->ll_weight * c.inv_b;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = 0; ch < nck; ++ch) {
       relaunder(c);
-      const int d0 = ch * PW;
-      const int valid = min(PW, D - d0);
-      tr(c, 16);
-      if (c.tid < PW) c.colacc[c.tid] = 0.f;
-      // x_hat chunk: acc[d][r]
+      const int d0 = ch * OCH;
+      const int valid = min(OCH, D - d0);
+      char* const slot = (ch & 1) ? slotA : Sb;
+      char* const other = (ch & 1) ? Sb : slotA;
+      const __bf16* Wc = reinterpret_cast<const __bf16*>(slot);
+      const float* vb = reinterpret_cast<const float*>(slot + OIMG_BYTES);      // bias[64], then logvar_out[64]
+      if (c.tid < OCH) c.colacc[c.tid] = 0.f;
+      wait_vm(0);                                 // chunk ch's blob (requested a chunk ago) and everything older
+      lds_barrier();                              // ... for every wave; also: the previous chunk is finished everywhere
+      if (ch + 1 < nck) dma_lin(c, oblob + (int64_t)(ch + 1) * OBLOB_BYTES, other, OBLOB_BYTES >> 10);
+      // fp32 inputs of the residual (rows are always inside the zero-padded table): in flight during the MFMAs
+      const int dl0 = c.wn * 16 + 4 * c.g;        // first of the lane's 4 columns inside the chunk
+      const int dg0 = d0 + dl0;
+      f32x4 xin[RT];
+      {
+        const int dcl = min(dg0, xp - 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
+      }
+      // x_hat chunk: acc[rt] = features dl0..dl0+3 of row (wm, rt, c16)
+      f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         const int ksteps = wpad(Hl) / 32;
-        // everything this chunk reads from memory is requested first: the chunk's weight rows (contiguous:
-        // coalesced copy into a bf16 tile in Q, free until the epilogue), the fp32 inputs of the residual
-        // (rows are always inside the zero-padded table) and logvar_out
-        const int Kpo = kpitch(Hl);
-        WBlk<128> wsg;
-        wblk_load<128>(c, wsg, Wo + (int64_t)d0 * Kpo, valid, Kpo, 0, 0);
-        f32x4 xin[RT];                     // inputs of feature tile t = 0 now, t = 1 after tile 0's epilogue
-        float sv[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int dg0 = d0 + (c.wn + 4 * t) * 16 + 4 * c.g;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) sv[t][i] = lvo[min(dg0 + i, D - 1)];
-        }
-        {
-          const int dcl = min(d0 + c.wn * 16 + 4 * c.g, xp - 4);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
-        }
-        prof(c, PH_X_LOADS);
-        tr(c, 18);
-        f32x4 acc[2][RT];
-        bias_acc(c, acc, bo, D, d0);
-        wblk_store<128>(c, wsg, c.Q, LDP, valid, Kpo, 0, 0);
-        lds_barrier();
-        tr(c, 17);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           if (ks < ksteps) {
-            bf16x8 wf[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.Q, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+            const bf16x8 wf = lds_frag(Wc, LDP, c.wn * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
               bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
-#pragma unroll
-              for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
+              acc[rt] = mfma(wf, a, acc[rt]);
             }
           }
         }
-        lds_barrier();                     // the weight tile is fully read: the epilogue (delta) or the next chunk's tile may overwrite Q
-        prof(c, PH_X_MFMA);
-        tr(c, 19);
-        // epilogue: residual, NLL, d logvar_out, delta chunk -> Q.  Lane: 4 consecutive ROI of one row.
+      }
+      tr(c, 6);
+      // epilogue: residual, NLL, d logvar_out, delta chunk -> Dq.  Lane: 4 consecutive ROI of one row.
+      {
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(vb + dl0);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(vb + OCH + dl0);
+        // per column: q = sum_r diff^2 (valid rows only).  Then  NLL = sum_d [0.5 e^{-s} q + n (0.5 s + log sqrt(2 pi))]
+        // and d(-LL)/d s_d = (0.5 n - 0.5 e^{-s} q) / B: one masked square-accumulate per element instead of
+        // evaluating both sums element by element.
+        float inv[4], colq[4], coef[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int dl0 = (c.wn + 4 * t) * 16 + 4 * c.g;       // first of the lane's 4 columns inside the chunk
-          const int dg0 = d0 + dl0;
-          // per column: q = sum_r diff^2 (valid rows only).  Then  NLL = sum_d [0.5 e^{-s} q + n (0.5 s + log sqrt(2 pi))]
-          // and d(-LL)/d s_d = (0.5 n - 0.5 e^{-s} q) / B: one masked square-accumulate per element instead of
-          // evaluating both sums element by element.
-          float inv[4], colq[4], coef[4];
+        for (int i = 0; i < 4; ++i) {
+          inv[i] = expf(-sv[i]);
+          colq[i] = 0.f;
+          coef[i] = (dg0 + i < D) ? llw_b * inv[i] : 0.f;                      // d total / d x_hat = coef * diff
+        }
+        int nvalid = 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int r = c.wm * WROWS + rt * 16 + c.c16;
+          const bool rv = r < c.nrows;
+          nvalid += rv ? 1 : 0;
+          acc[rt] += bo;                                                       // x_hat
+          bf16x4 pk;
+          f32x4 ex = {0.f, 0.f, 0.f, 0.f};
+          if (md.dloc_extra)               // extra loss gradient on x_hat (regression head)
+            ex = *(const GAS f32x4*)(asg(md.dloc_extra) + (int64_t)(c.row0 + r) * xp + min(dg0, xp - 4));
+          float rc = 0.f;
+          if (md.dloc_rowcoef) rc = asg(md.dloc_rowcoef)[c.row0 + r];      // contrastive hinge: rc * (x_hat - x)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            inv[i] = expf(-sv[t][i]);
-            colq[i] = 0.f;
-            coef[i] = (dg0 + i < D) ? llw_b * inv[i] : 0.f;                      // d total / d x_hat = coef * diff
+            const float diff = rv ? acc[rt][i] - xin[rt][i] : 0.f;
+            colq[i] = fmaf(diff, diff, colq[i]);
+            const bool dv = dg0 + i < D;
+            pk[i] = (__bf16)(diff * (coef[i] + (dv ? rc : 0.f)) + ((rv && dv) ? ex[i] : 0.f));
           }
-          f32x4 xcur[RT];
+          if (bwd) *reinterpret_cast<bf16x4*>(Dq + r * LDX + dl0) = pk;
+        }
+        float colsum[4];
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) xcur[rt] = xin[rt];
-          if (t == 0) {                      // request tile 1's inputs while tile 0 is processed
-            const int dcl = min(d0 + (c.wn + 4) * 16 + 4 * c.g, xp - 4);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-              xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
-          }
-          int nvalid = 0;
+        for (int i = 0; i < 4; ++i) {
+          const bool dv = dg0 + i < D;
+          const float hq = 0.5f * inv[i] * colq[i];
+          nll_part += dv ? hq + (float)nvalid * (0.5f * sv[i] + LOG_SQRT_2PI) : 0.f;
+          colsum[i] = dv ? 0.5f * (float)nvalid - hq : 0.f;
+        }
+        if (exportf && dg0 < xp) {           // exports share the fp32 table's row pitch: one 16-byte store each
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const int r = c.wm * WROWS + rt * 16 + c.c16;
-            const bool rv = r < c.nrows;
-            nvalid += rv ? 1 : 0;
-            bf16x4 pk;
-            f32x4 ex = {0.f, 0.f, 0.f, 0.f};
-            if (md.dloc_extra)               // extra loss gradient on x_hat (regression head)
-              ex = *(const GAS f32x4*)(asg(md.dloc_extra) + (int64_t)(c.row0 + r) * xp + min(dg0, xp - 4));
-            float rc = 0.f;
-            if (md.dloc_rowcoef) rc = asg(md.dloc_rowcoef)[c.row0 + r];      // contrastive hinge: rc * (x_hat - x)
+            if (r < c.nrows) {
+              f32x4 lo, sq;
+              float rs = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float diff = rv ? acc[t][rt][i] - xcur[rt][i] : 0.f;
-              colq[i] = fmaf(diff, diff, colq[i]);
-              const bool dv = dg0 + i < D;
-              pk[i] = (__bf16)(diff * (coef[i] + (dv ? rc : 0.f)) + ((rv && dv) ? ex[i] : 0.f));
+              for (int i = 0; i < 4; ++i) {
+                const bool dv = dg0 + i < D;
+                const float xh = acc[rt][i], diff = xh - xin[rt][i];
+                lo[i] = dv ? xh : 0.f;
+                sq[i] = dv ? diff * diff : 0.f;
+                rs += sq[i];
+              }
+              const int64_t gi = (int64_t)(c.row0 + r) * xp + dg0;
+              if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
+              if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
+              if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
             }
-            if (bwd) *reinterpret_cast<bf16x4*>(c.Q + r * LDP + dl0) = pk;
           }
-          float colsum[4];
+        }
+        if (bwd) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const bool dv = dg0 + i < D;
-            const float hq = 0.5f * inv[i] * colq[i];
-            nll_part += dv ? hq + (float)nvalid * (0.5f * sv[t][i] + LOG_SQRT_2PI) : 0.f;
-            colsum[i] = dv ? 0.5f * (float)nvalid - hq : 0.f;
-          }
-          if (exportf && dg0 < xp) {           // exports share the fp32 table's row pitch: one 16-byte store each
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-              const int r = c.wm * WROWS + rt * 16 + c.c16;
-              if (r < c.nrows) {
-                f32x4 lo, sq;
-                float rs = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const bool dv = dg0 + i < D;
-                  const float xh = acc[t][rt][i], diff = xh - xcur[rt][i];
-                  lo[i] = dv ? xh : 0.f;
-                  sq[i] = dv ? diff * diff : 0.f;
-                  rs += sq[i];
-                }
-                const int64_t gi = (int64_t)(c.row0 + r) * xp + dg0;
-                if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
-                if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
-                if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
-              }
-            }
-          }
-          if (bwd) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float s = colsum[i];
-              s += __shfl_xor(s, 1, 64);
-              s += __shfl_xor(s, 2, 64);
-              s += __shfl_xor(s, 4, 64);
-              s += __shfl_xor(s, 8, 64);
-              if (c.c16 == 0 && dg0 + i < D) atomicAdd(&c.colacc[dl0 + i], s);
-            }
+            float s = colsum[i];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (c.c16 == 0 && dg0 + i < D) atomicAdd(&c.colacc[dl0 + i], s);
           }
         }
       }
       prof(c, PH_X_EPI);
-      tr(c, 20);
-      if (!bwd) continue;
-      // dgrad into the last hidden activation: accg[k][r] += sum_d Q[r][d] Wo[d0 + d][k].  The chunk's weight
-      // rows come back from L2 (the forward tile was copied from them) as two 64-row half tiles through the
-      // gradient slab, read with the transposing LDS load; both halves are requested now.
+      tr(c, 7);
+      if (!bwd) continue;                         // forward only: the next chunk's barrier protects the slots
+      lds_barrier();                              // delta chunk and column sums complete
       relaunder(c);
-      __bf16* Th = reinterpret_cast<__bf16*>(c.stage);
-      const int Kph = kpitch(Hl);
-      const int rows_a = min(valid, 64), rows_b = valid - rows_a;
-      WBlk<64> ha, hb;
-      wblk_load<64>(c, ha, Wo + (int64_t)d0 * Kph, valid, Kph, 0, 0);
-      wblk_load<64>(c, hb, Wo + (int64_t)d0 * Kph, valid, Kph, 64, 0);      // rows clamp to the chunk's last row
-      wblk_store<64>(c, ha, Th, LDP, valid, Kph, 0, 0);
-      lds_barrier();                              // delta chunk in Q and half tile A complete
-      tr(c, 21);
-      prof(c, PH_OUT_GEMM);
-      // d logvar_out for this chunk
-      if (c.tid < valid) apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b);
-      prof(c, PH_OUT_DLV);
-      dgrad_tile(c, accg, c.Q, 0, Th, LDP, rup(rows_a, 32) / 32);
-      if (rows_b > 0) {
-        lds_barrier();                            // half A fully read
-        wblk_store<64>(c, hb, Th, LDP, valid, Kph, 64, 0);
-        lds_barrier();
-        dgrad_tile(c, accg, c.Q, 64, Th, LDP, rup(rows_b, 32) / 32);
-      }
-      tr(c, 34);
-      lds_barrier();                              // the slab is free again; old Wo fully read
-      tr(c, 35);
+      // d logvar_out for this chunk (master + the copy that travels with the chunk's image)
+      if (c.tid < valid)
+        apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b,
+                   (GAS float*)(oblob + (int64_t)ch * OBLOB_BYTES + OIMG_BYTES) + OCH + c.tid);
+      // dgrad into the last hidden activation: accg[k][r] += sum_d Dq[r][d] Wo[d0 + d][k], weights from the slot
+      dgrad_tile(c, accg, Dq, LDX, 0, Wc, LDP, OCH / 32);
+      tr(c, 8);
       prof(c, PH_OUT_DGRAD);
-      // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Q[r][d] P[r][k]
-      wgrad_adam<SCALAR_TR>(c, c.Q, LDP, 0, c.P, LDP, valid, Hl, 0, rup(Hl + 1, 16),
-                            md.out_w + (int64_t)d0 * kpitch(Hl), md.out_b + d0);
+      // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Dq[r][d] P[r][k]
+      {
+        GAS char* img = wsh + md.out_s + (int64_t)ch * OBLOB_BYTES;
+        WgT T{md.out_w + (int64_t)(d0 >> 4) * KTo * 256, md.out_b + d0, img, LDP * 2, (GAS float*)(img + OIMG_BYTES), opatch};
+        wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, valid, Hl, 0, rup(Hl + 1, 16), T);
+      }
+      tr(c, 9);
       prof(c, PH_OUT_WGRAD);
     }
     float nll = block_sum(c, nll_part);
@@ -1306,38 +1362,34 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       lds_barrier();
       for (int r = c.tid; r < c.nrows; r += WG) asg(md.out_rowdev)[c.row0 + r] = c.rowacc[r] / (float)D;
     }
-    if (!bwd) { __syncthreads(); continue; }
+    if (!bwd) { lds_barrier(); continue; }
 
     // --- decoder hidden layers, backward ---
     // state: P = activation g_{L-1}, accg = pre-mask delta of g_{L-1}
-    tr(c, 43);
     finish_delta(c, accg, c.P, Hl, nl);             // mask source is P itself (same element)
-    tr(c, 44);
     lds_barrier();
-    tr(c, 45);
     prof(c, PH_DEC_FINISH);
+    float* const spatch = reinterpret_cast<float*>(Sb + SPATCH_OFF);
     for (int d = L - 1; d >= 0; --d) {
       relaunder(c);
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
-      // dgrad from the layer's weight tile staged in Q, then Q <- input activation of decoder layer d
       f32x4 acc[2][RT];
       zero_acc(acc);
-      dgrad_staged(c, acc, c.P, prm + md.dec_w[d], Nout, Kin);
-      tr(c, 34);
-      lds_barrier();                              // weight tile fully read
-      tr(c, 35);
+      const GAS char* act_img = d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ACT_BYTES;
+      dgrad_hidden(c, acc, wsh + md.dec_s[d], act_img, Nout);
+      tr(c, 10);
       prof(c, PH_DEC_DGRAD);
-      tr(c, 31);
-      load_act(c, c.Q, d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ROWS * PW, wpad(Kin));
-      tr(c, 32);
-      lds_barrier();
-      tr(c, 36);
-      prof(c, PH_DEC_LOAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.dec_w[d], md.dec_b[d]);
+      {
+        GAS char* img = wsh + md.dec_s[d];
+        WgT T{md.dec_w[d], md.dec_b[d], img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch};
+        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), T);
+      }
+      tr(c, 11);
       prof(c, PH_DEC_WGRAD);
       if (d > 0) {
         finish_delta(c, acc, c.Q, Kin, nl);
+        lds_barrier();
       } else {
         // d z: accumulate over decoders (fixed element -> thread ownership, no race)
         const int ntk = wpad(Kin) / 16;
@@ -1355,8 +1407,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             }
           }
         }
+        lds_barrier();
       }
-      __syncthreads();
       prof(c, PH_DEC_DELTA);
     }
   }
@@ -1370,10 +1422,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
   if (!bwd) return;
   prof(c, PH_ALPHA);
+  handoff_barrier();                              // d z of every decoder is complete
 
   // ================= fusion backward: alpha gradients (gPoE) =================
   const bool fused = !(Me == 1 && J->single_bypass);
   const float klw = J->kl_weight * c.inv_b;
+  gbf16 ws_fz = (gbf16)ws_zc;                     // the (dead) z|c slot, legacy [256][PW] layout
   // With several experts the fusion backward (8 exponentials per element) is evaluated ONCE: the deltas of every
   // expert go side by side into Q (expert m in columns [m 2Zs, (m+1) 2Zs) = [d mu_m | d logvar_m]), from there into
   // the (dead) z|c slot of the workspace, and each encoder's backward below starts from a 16-byte copy of its
@@ -1420,28 +1474,33 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         for (int m = 0; m < NM_MAX_EXP; ++m) dot += al[m] * tot[m];
 #pragma unroll
         for (int m = 0; m < NM_MAX_EXP; ++m)
-          if (m < Me) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot));   // softmax backward
+          if (m < Me) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot), nullptr);   // softmax backward
       }
     }
     lds_barrier();
-    if (once) store_act(c, ws_zc, c.Q, Me * 2 * Zs);
-    __syncthreads();
+    if (once) store_act(c, ws_fz, c.Q, Me * 2 * Zs);
+    handoff_barrier();
   }
+  tr(c, 12);
 
   // ================= encoders, backward =================
+  float* const spatch = reinterpret_cast<float*>(Sb + SPATCH_OFF);
   for (int m = 0; m < Me; ++m) {
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int Hh = J->H[L - 1];
     const int whp = rup(2 * Zs, 32);
-    const float rwh = 1.0f / (float)whp;
-    // P <- [d mu_m | 0 | d logvar_m | 0], Q <- last hidden activation
+    // heads image -> lower half of Q, upper rows of the last hidden activation -> upper half: in flight while
+    // P <- [d mu_m | 0 | d logvar_m | 0] is put together
+    const GAS char* act_last = ws_enc + (int64_t)(m * L + (L - 1)) * ACT_BYTES;
+    dma_lin(c, wsh + md.heads_s, Qb, IMG_BYTES >> 10);
+    dma_lin(c, act_last + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
     if (once) {                                    // this expert's columns of the saved fusion backward
       const int segs = (2 * Zs) >> 3;              // 16-byte pieces per row
       const float rs_ = 1.0f / (float)segs;
       for (int p_ = c.tid; p_ < ROWS * segs; p_ += WG) {
         const int row = idiv(p_, segs, rs_), seg = p_ - row * segs;
-        *reinterpret_cast<u32x4*>(c.P + row * LDP + seg * 8) = *(const GAS u32x4*)(ws_zc + row * PW + m * 2 * Zs + seg * 8);
+        *reinterpret_cast<u32x4*>(c.P + row * LDP + seg * 8) = *(const GAS u32x4*)(ws_fz + row * PW + m * 2 * Zs + seg * 8);
       }
     } else {
       const int npad = whp - 2 * Z;
@@ -1466,22 +1525,26 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         c.P[r * LDP + Zs + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
       }
     }
-    tr(c, 37);
-    // dgrad through both heads from one staged tile (rows = [d mu | d logvar] columns of P), then Q <- activation
-    stage_heads(c, c.Q, prm + md.mu_w, prm + md.lv_w, Z, Hh, Zs);
+    wait_vm(0);
     lds_barrier();
     prof(c, PH_ENCB_PREP);
+    // dgrad through both heads from one image (rows = [d mu | d logvar] columns of P), then Q <- activation
     f32x4 acc[2][RT];
     zero_acc(acc);
-    dgrad_tile(c, acc, c.P, 0, c.Q, LDP, (2 * Zs) / 32);
-    lds_barrier();                                  // tile fully read
+    dgrad_tile(c, acc, c.P, LDP, 0, c.Q, LDP, (2 * Zs) / 32);
+    lds_barrier();                                  // image fully read
     prof(c, PH_ENCB_HEADS_DGRAD);
-    load_act(c, c.Q, ws_enc + (int64_t)(m * L + (L - 1)) * ROWS * PW, wpad(Hh));
-    tr(c, 38);
+    dma_lin(c, act_last, Qb, IMG_BYTES >> 10);
+    wait_vm(0);
     lds_barrier();
-    tr(c, 39);
-    wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.mu_w, md.mu_b);
-    wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), md.lv_w, md.lv_b);
+    tr(c, 13);
+    {
+      GAS char* img = wsh + md.heads_s;
+      WgT Tm{md.mu_w, md.mu_b, img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch};
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), Tm);
+      WgT Tl{md.lv_w, md.lv_b, img + (int64_t)Zs * LDP * 2, LDP * 2, (GAS float*)(img + IMG_BYTES) + Zs, spatch};
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), Tl);
+    }
     prof(c, PH_ENCB_HEADS_WGRAD);
     finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
     lds_barrier();
@@ -1489,47 +1552,55 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     for (int e = L - 1; e >= 1; --e) {
       int Kin = J->H[e - 1], Nout = J->H[e];
       zero_acc(acc);
-      dgrad_staged(c, acc, c.P, prm + md.enc_w[e], Nout, Kin);
-      lds_barrier();                              // weight tile fully read
+      dgrad_hidden(c, acc, wsh + md.enc_s[e], ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout);
       prof(c, PH_ENCB_DGRAD);
-      load_act(c, c.Q, ws_enc + (int64_t)(m * L + (e - 1)) * ROWS * PW, wpad(Kin));
-      lds_barrier();
-      prof(c, PH_ENCB_LOAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), md.enc_w[e], md.enc_b[e]);
+      {
+        GAS char* img = wsh + md.enc_s[e];
+        WgT T{md.enc_w[e], md.enc_b[e], img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch};
+        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), T);
+      }
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
       lds_barrier();
       prof(c, PH_ENCB_DELTA);
     }
-    // first encoder layer: dW[n][k] = sum_r P[r][n] xc[r][k], x streamed through Q
+    tr(c, 14);
+    // first encoder layer: dW[n][k] = sum_r P[r][n] xc[r][k]; the x chunk images stream through two slots of Q
+    // (the second one runs 4 KiB into S, below the patches): chunk kc + 1 lands while chunk kc is processed
     {
       const int Kx = md.Kx, K0 = md.D + C, N0 = J->H[0];
       const int nch = (Kx + XCH - 1) / XCH;
-      XStage st;
-      xchunk_load(c, st, asg(md.xb), Kx, 0);
+      const GAS char* xsrc = (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * nch * XIMG_BYTES;
+      GAS char* img = wsh + md.enc_s[0];
+      dma_lin<0>(c, xsrc, Qb, XIMG_BYTES >> 10);
       for (int kc = 0; kc < nch; ++kc) {
-        tr(c, 40);
-        xchunk_store(c, st, c.Q);
-        tr(c, 41);
-        lds_barrier();
-        tr(c, 42);
-        if (kc + 1 < nch) xchunk_load(c, st, asg(md.xb), Kx, kc + 1);
+        wait_vm(0);
+        lds_barrier();                            // chunk kc has landed everywhere; chunk kc - 1 is finished everywhere
+        if (kc + 1 < nch) dma_lin<0>(c, xsrc + (int64_t)(kc + 1) * XIMG_BYTES, Qb + ((kc + 1) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
+        const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + (kc & 1) * XIMG_BYTES);
         int cols = min(XCH, Kx - kc * XCH);
-        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDX, N0, K0, kc * XCH, cols, md.enc_w[0], md.enc_b[0]);
+        WgT T{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * W0IMG_BYTES, LDX * 2,
+              (GAS float*)(img + (int64_t)nch * W0IMG_BYTES), spatch};
+        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, N0, K0, kc * XCH, cols, T);
       }
       prof(c, PH_ENCB_L0_WGRAD);
     }
+    tr(c, 15);
   }
 }
 
 // ----------------------------------------------------------------------------------------------
-constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + (STAGE_FLOATS + 64 + 128 + 256 + 16) * 4;
+constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + STAGE_FLOATS * 4 + 2 * VEC_BYTES + (64 + 128 + 256 + 16) * 4;
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+static_assert(XIMG_BYTES + OBLOB_BYTES + NWAVES * PATCH_FLOATS * 4 <= ACT_BYTES, "output-chunk layout of Q");
+static_assert(2 * XIMG_BYTES - ACT_BYTES <= SPATCH_OFF && SPATCH_OFF + NWAVES * PATCH_FLOATS * 4 <= STAGE_FLOATS * 4, "S layout");
 
 __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
   c.P = reinterpret_cast<__bf16*>(smem);
   c.Q = c.P + ROWS * LDP;
   c.stage = reinterpret_cast<float*>(c.Q + ROWS * LDP);
-  c.red = c.stage + STAGE_FLOATS;
+  c.vec = c.stage + STAGE_FLOATS;
+  c.red = c.vec + 2 * (VEC_BYTES / 4);
   c.colacc = c.red + 64;
   c.rowacc = c.colacc + 128;
   c.tlast = reinterpret_cast<unsigned long long*>(c.rowacc + 256);
@@ -1551,10 +1622,10 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   // De-phase the workgroups of a long launch: identical models otherwise run their HBM-heavy weight-gradient /
-  // Adam phases in lockstep and share the DRAM 256 ways at once (measured: -3 % per step; the sleep itself costs
-  // up to 7/8 of one step per launch, hence only for launches of 64 steps or more).
-  if (steps_per_tile >= 64 && J->dephase > 0)
-    for (int i = 0; i < (int)(blockIdx.x & 7) * J->dephase; ++i) __builtin_amdgcn_s_sleep(127);
+  // Adam phases in lockstep and share the DRAM 256 ways at once (the sleep itself costs up to 7/8 of one step per
+  // launch, hence only for launches of 64 steps or more).
+  if (steps_per_tile >= 64)
+    for (int i = 0; i < J->dephase; ++i) __builtin_amdgcn_s_sleep(127);
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
   const int s_begin = step0 + blockIdx.y * steps_per_tile;
   for (int s = s_begin; s < s_begin + steps_per_tile; ++s) {
@@ -1572,7 +1643,8 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     relaunder(c);
     run_step<SCALAR_TR>(c, s);
     tr(c, 62);
-    __syncthreads();
+    // the next step reads what this one stored (weights, shadow images, workspace): drain, then meet
+    handoff_barrier();
     tr(c, 63);
   }
 }
@@ -1683,7 +1755,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   // W1 through P (free until h1 exists), both as coalesced copies; next block's weights fly during the MFMAs ----
   f32x4 acc[2][RT];
   bias_acc(c, acc, b1, N1, 0);
-  const int Kp1 = kpitch(SD);
+  const int Kp1 = SD;                            // wblk_* take the matrix's K (tiled master)
   WBlk<128> wb;
   wblk_load<128>(c, wb, W1, N1, Kp1, 0, 0);
   for (int ch = 0; ch < nch; ++ch) {
@@ -1732,7 +1804,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   float pred = 0.f, err = 0.f;
   if (c.tid < ROWS) {
     float s = prm[J->reg_b[2]];
-    for (int n = 0; n < N2; ++n) s = fmaf((float)c.P[c.tid * LDP + n], (float)(__bf16)W3[n], s);
+    for (int n = 0; n < N2; ++n) s = fmaf((float)c.P[c.tid * LDP + n], (float)(__bf16)W3[wt_off(0, n, N2 / 16)], s);
     pred = s;
     if (c.tid < c.nrows) {
       if (J->out_fi_pred) asg(J->out_fi_pred)[c.row0 + c.tid] = pred;
@@ -1758,10 +1830,10 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   for (int e = c.tid; e < ROWS * N2; e += WG) {
     const int r = e >> 6, n = e & 63;
     const float h = (float)c.P[r * LDP + n];
-    c.P[r * LDP + n] = (__bf16)(h > 0.f ? c.rowacc[r] * (float)(__bf16)W3[n] : 0.f);
+    c.P[r * LDP + n] = (__bf16)(h > 0.f ? c.rowacc[r] * (float)(__bf16)W3[wt_off(0, n, N2 / 16)] : 0.f);
   }
   __syncthreads();                               // W3 fully read before its update
-  if (c.tid < N2) apply_grad(c, J->reg_w[2] + c.tid, g3);
+  if (c.tid < N2) apply_grad(c, J->reg_w[2] + wt_off(0, c.tid, N2 / 16), g3);
   else if (c.tid == N2) apply_grad(c, J->reg_b[2], g3);
   if (c.tid < N2) {                              // db2 = column sums of delta h2
     float g = 0.f;
@@ -1774,7 +1846,8 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   zero_acc(acc);
   dgrad_acc(c, acc, c.P, W2, N2, N1, N2 / 32, 0);
   lds_barrier();                                 // W2 fully read before its update
-  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N2, N1, 0, N1, J->reg_w[1], -1);
+  float* const hpatch = c.stage + SPATCH_OFF / 4;
+  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N2, N1, 0, N1, WgT{J->reg_w[1], -1, nullptr, 0, nullptr, hpatch});
   relaunder(c);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {                  // P <- delta h1 = acc * relu'(h1)
@@ -1808,11 +1881,11 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
     wblk_store<64>(c, ha, Th, LDP, N1, Kp1, 0, k0);
     lds_barrier();
     zero_acc(acc);
-    dgrad_tile(c, acc, c.P, 0, Th, LDP, 2);
+    dgrad_tile(c, acc, c.P, LDP, 0, Th, LDP, 2);
     lds_barrier();
     wblk_store<64>(c, hb, Th, LDP, N1, Kp1, 64, k0);
     lds_barrier();
-    dgrad_tile(c, acc, c.P, 64, Th, LDP, 2);
+    dgrad_tile(c, acc, c.P, LDP, 64, Th, LDP, 2);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -1833,7 +1906,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
       }
     }
     lds_barrier();                               // W1 chunk fully read before its update
-    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N1, SD, k0, rup(valid, 16), J->reg_w[0], -1);
+    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N1, SD, k0, rup(valid, 16), WgT{J->reg_w[0], -1, nullptr, 0, nullptr, hpatch});
   }
 }
 
@@ -2109,7 +2182,8 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   float gb = 0.f;
   if (c.tid < C) for (int r = 0; r < ROWS; ++r) gb += (float)c.P[r * LDP + c.tid];
   lds_barrier();                                   // Wo fully read before its update
-  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, C, Kl, 0, rup(Kl, 16), J->cls_w[Lc], -1);
+  float* const hpatch = c.stage + SPATCH_OFF / 4;
+  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, C, Kl, 0, rup(Kl, 16), WgT{J->cls_w[Lc], -1, nullptr, 0, nullptr, hpatch});
   if (c.tid < C) apply_grad(c, J->cls_b[Lc] + c.tid, gb);
   // ---- backward: hidden blocks ----
   for (int li = Lc - 1; li >= 0; --li) {
@@ -2181,7 +2255,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
     zero_acc(acc);
     dgrad_acc(c, acc, c.P, Wl, N, K, rup(N, 32) / 32, 0);
     lds_barrier();
-    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N, K, 0, rup(K, 16), J->cls_w[li], -1);
+    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N, K, 0, rup(K, 16), WgT{J->cls_w[li], -1, nullptr, 0, nullptr, hpatch});
     if (c.tid < N) apply_grad(c, J->cls_b[li] + c.tid, gbi);
   }
   // ---- d CE / d z ----
@@ -2214,20 +2288,102 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
   }
 }
 
+// Shadow images from the fp32 master: one workgroup per job.  A matrix is walked in master (tile) order; element
+// (n, k) goes to image row row0 + n, column k of `img` (row pitch `pitch` bytes), k-chunked every `kchunk` columns
+// with `kstride` bytes between chunk images, n-chunked every `nchunk` rows with `nstride` bytes between chunk blobs.
+__device__ __forceinline__ void sync_matrix(const float* prm, int64_t w_off, int N, int K, char* img, int pitch, int kchunk,
+                                            int64_t kstride, int nchunk, int64_t nstride) {
+  const int KT = ktiles(K);
+  const int64_t total = wt_elems(N, K);
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int tile = (int)(e >> 8), r = (int)(e >> 4) & 15, cidx = (int)e & 15;
+    const int n = (tile / KT) * 16 + r, k = (tile % KT) * 16 + cidx;
+    const __bf16 h = (__bf16)prm[w_off + e];
+    char* dst = img + (int64_t)(k / kchunk) * kstride + (int64_t)(n / nchunk) * nstride + (int64_t)(n % nchunk) * pitch +
+                (k % kchunk) * 2;
+    *reinterpret_cast<__bf16*>(dst) = h;
+  }
+}
+__global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
+  const nm_job_t* J = jobs + blockIdx.x;
+  const float* prm = J->params;
+  char* wsh = (char*)J->wsh;
+  if (!wsh) return;
+  const int L = J->L, Z = J->Z, C = J->C, Zs = rup(Z, 16);
+  const int Me = J->M_enc > 0 ? J->M_enc : J->M;
+  const int BIG = 1 << 30;
+  for (int m = 0; m < J->M; ++m) {
+    const nm_modality_t& md = J->mod[m];
+    if (m < Me) {
+      const int nch = (md.Kx + XCH - 1) / XCH;
+      sync_matrix(prm, md.enc_w[0], J->H[0], md.D + C, wsh + md.enc_s[0], LDX * 2, XCH, W0IMG_BYTES, BIG, 0);
+      float* b0 = (float*)(wsh + md.enc_s[0] + (int64_t)nch * W0IMG_BYTES);
+      for (int i = threadIdx.x; i < J->H[0]; i += blockDim.x) b0[i] = prm[md.enc_b[0] + i];
+      for (int e = 1; e < L; ++e) {
+        sync_matrix(prm, md.enc_w[e], J->H[e], J->H[e - 1], wsh + md.enc_s[e], LDP * 2, BIG, 0, BIG, 0);
+        float* b = (float*)(wsh + md.enc_s[e] + IMG_BYTES);
+        for (int i = threadIdx.x; i < J->H[e]; i += blockDim.x) b[i] = prm[md.enc_b[e] + i];
+      }
+      sync_matrix(prm, md.mu_w, Z, J->H[L - 1], wsh + md.heads_s, LDP * 2, BIG, 0, BIG, 0);
+      sync_matrix(prm, md.lv_w, Z, J->H[L - 1], wsh + md.heads_s + (int64_t)Zs * LDP * 2, LDP * 2, BIG, 0, BIG, 0);
+      float* bh = (float*)(wsh + md.heads_s + IMG_BYTES);
+      for (int i = threadIdx.x; i < Z; i += blockDim.x) { bh[i] = prm[md.mu_b + i]; bh[Zs + i] = prm[md.lv_b + i]; }
+    }
+    for (int d = 0; d < L; ++d) {
+      const int Kin = d == 0 ? Z + C : J->H[L - d], Nout = J->H[L - 1 - d];
+      sync_matrix(prm, md.dec_w[d], Nout, Kin, wsh + md.dec_s[d], LDP * 2, BIG, 0, BIG, 0);
+      float* b = (float*)(wsh + md.dec_s[d] + IMG_BYTES);
+      for (int i = threadIdx.x; i < Nout; i += blockDim.x) b[i] = prm[md.dec_b[d] + i];
+    }
+    sync_matrix(prm, md.out_w, md.D, J->H[0], wsh + md.out_s, LDP * 2, BIG, 0, OCH, OBLOB_BYTES);
+    for (int i = threadIdx.x; i < md.D; i += blockDim.x) {
+      float* vb = (float*)(wsh + md.out_s + (int64_t)(i / OCH) * OBLOB_BYTES + OIMG_BYTES);
+      vb[i % OCH] = prm[md.out_b + i];
+      vb[OCH + i % OCH] = prm[md.logvar_out + i];
+    }
+  }
+}
+
+// xb images [tile][chunk][256][LDX] (x | c | 1 | 0 in 64-column chunks, 8 pad columns per row), the fp32 copy of x
+// and the covariate block cz = c | 1 | 0.
 __global__ void pack_table_kernel(const float* __restrict__ x, const float* __restrict__ cc, int n_rows, int rows_alloc,
-                                  int D, int C, int Kx, uint16_t* __restrict__ xb, float* __restrict__ xf, int xp) {
-  int64_t total = (int64_t)rows_alloc * Kx;
+                                  int D, int C, int Kx, uint16_t* __restrict__ xb, float* __restrict__ xf, int xp,
+                                  uint16_t* __restrict__ cz, int Cz) {
+  const int nch = (Kx + XCH - 1) / XCH;
+  const int64_t total = (int64_t)rows_alloc * nch * LDX;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int r = (int)(i / Kx), k = (int)(i - (int64_t)r * Kx);
+    // i -> (tile, chunk, row in tile, column in chunk)
+    const int j = (int)(i % LDX);
+    const int64_t q = i / LDX;
+    const int rl = (int)(q % ROWS);
+    const int64_t q2 = q / ROWS;
+    const int kc = (int)(q2 % nch), tile = (int)(q2 / nch);
+    const int r = tile * ROWS + rl, k = kc * XCH + j;
     float v = 0.f;
-    if (r < n_rows) {
+    if (r < n_rows && j < XCH) {
       if (k < D) v = x[(int64_t)r * D + k];
       else if (k < D + C) v = cc[(int64_t)r * C + (k - D)];
       else if (k == D + C) v = 1.0f;
     }
     __bf16 h = (__bf16)v;
     xb[i] = __builtin_bit_cast(uint16_t, h);
-    if (xf && k < xp) xf[(int64_t)r * xp + k] = (r < n_rows && k < D) ? x[(int64_t)r * D + k] : 0.f;
+  }
+  if (xf) {
+    const int64_t tf = (int64_t)rows_alloc * xp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tf; i += (int64_t)gridDim.x * blockDim.x) {
+      const int r = (int)(i / xp), k = (int)(i - (int64_t)r * xp);
+      xf[i] = (r < n_rows && k < D) ? x[(int64_t)r * D + k] : 0.f;
+    }
+  }
+  if (cz) {
+    const int64_t tc = (int64_t)rows_alloc * Cz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tc; i += (int64_t)gridDim.x * blockDim.x) {
+      const int r = (int)(i / Cz), k = (int)(i - (int64_t)r * Cz);
+      float v = 0.f;
+      if (r < n_rows) v = k < C ? cc[(int64_t)r * C + k] : (k == C ? 1.0f : 0.f);
+      __bf16 h = (__bf16)v;
+      cz[i] = __builtin_bit_cast(uint16_t, h);
+    }
   }
 }
 
@@ -2323,7 +2479,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 4; }
+int nm_version(void) { return 5; }
 
 /* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {
@@ -2365,10 +2521,12 @@ const char* nm_status_string(int status) {
     case -4: return "hidden width out of range (1..NM_MAX_WIDTH)";
     case -5: return "latent out of range (1..NM_MAX_LATENT)";
     case -6: return "latent + c_dim exceeds NM_MAX_WIDTH";
-    case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D";
+    case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
+    case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
+    case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
-    case -10: return "parameter tensor offsets must be multiples of 4 floats";
+    case -10: return "parameter tensor offsets must be multiples of 4 floats (weight matrices: of 256)";
     case -13: return "classifier head: 0..NM_MAX_CLS blocks of width 1..128, 2..NM_MAX_CLASSES classes, offsets multiples of 4, out_mu/out_z export";
     case -12: return "metrics: n_sets >= 1 and 1 <= max_set <= NM_METRICS_MAX_N";
     case -11: return "regression head: needs reg_w / reg_b offsets (multiples of 4) and every expert's out_loc export";
@@ -2386,30 +2544,66 @@ int nm_validate_job(const nm_job_t* j) {
   if (j->Z < 1 || j->Z > NM_MAX_LATENT) return -5;
   if (j->Z + j->C > NM_MAX_WIDTH) return -6;
   if (j->combine < 0 || j->combine > NM_COMBINE_MOPOE) return -9;
+  if (j->n_rows < 1 || j->loss_cap < 1 || j->eps_cap < 1) return -14;       // modulo divisors / batch count in the kernel
+  if (!j->wsh) return -15;
   for (int m = 0; m < j->M; ++m) {
     const nm_modality_t& md = j->mod[m];
-    if (md.Kx % 32 != 0 || md.Kx < md.D + j->C + 1) return -7;
+    if (md.D < 1 || md.Kx % 32 != 0 || md.Kx < md.D + j->C + 1) return -7;
     if (md.x_pitch % 4 != 0 || md.x_pitch < md.D) return -7;
-    for (int i = 0; i < j->L; ++i)
-      if ((md.enc_w[i] | md.enc_b[i] | md.dec_w[i] | md.dec_b[i]) & 3) return -10;
-    if ((md.mu_w | md.mu_b | md.lv_w | md.lv_b | md.logvar_out | md.out_w | md.out_b) & 3) return -10;
+    if (md.Cz % 8 != 0 || md.Cz < j->C + 1) return -7;
+    for (int i = 0; i < j->L; ++i) {
+      if ((md.enc_b[i] | md.dec_b[i]) & 3) return -10;
+      if ((md.enc_w[i] | md.dec_w[i]) & 255) return -10;
+    }
+    if ((md.mu_b | md.lv_b | md.logvar_out | md.out_b) & 3) return -10;
+    if ((md.mu_w | md.lv_w | md.out_w) & 255) return -10;
   }
   if (j->cls_classes > 0) {
     if (j->cls_layers < 0 || j->cls_layers > NM_MAX_CLS || j->cls_classes < 2 || j->cls_classes > NM_MAX_CLASSES) return -13;
     for (int i = 0; i < j->cls_layers; ++i) {
       if (j->cls_width[i] < 1 || j->cls_width[i] > PW) return -13;
-      if ((j->cls_w[i] | j->cls_b[i] | j->cls_bn_w[i] | j->cls_bn_b[i] | j->cls_bn_mean[i] | j->cls_bn_var[i]) & 3) return -13;
+      if ((j->cls_b[i] | j->cls_bn_w[i] | j->cls_bn_b[i] | j->cls_bn_mean[i] | j->cls_bn_var[i]) & 3) return -13;
+      if (j->cls_w[i] & 255) return -13;
     }
-    if ((j->cls_w[j->cls_layers] | j->cls_b[j->cls_layers]) & 3) return -13;
+    if ((j->cls_b[j->cls_layers] & 3) || (j->cls_w[j->cls_layers] & 255)) return -13;
     if (!(j->cls_use_mu ? j->out_mu : j->out_z)) return -13;
   }
   if (j->reg_head) {
     for (int i = 0; i < 3; ++i)
-      if (j->reg_w[i] < 0 || j->reg_b[i] < 0 || ((j->reg_w[i] | j->reg_b[i]) & 3)) return -11;
+      if (j->reg_w[i] < 0 || j->reg_b[i] < 0 || (j->reg_w[i] & 255) || (j->reg_b[i] & 3)) return -11;
     for (int m = 0; m < (j->M_enc == 0 ? j->M : j->M_enc); ++m)
       if (!j->mod[m].out_loc) return -11;
   }
   return 0;
+}
+
+int64_t nm_fill_shadow(nm_job_t* j) {
+  if (!j) return -1;
+  if (j->M < 1 || j->M > NM_MAX_MOD || j->L < 1 || j->L > NM_MAX_HID) return -2;
+  const int Me = j->M_enc > 0 ? j->M_enc : j->M;
+  int64_t o = 0;
+  for (int m = 0; m < j->M; ++m) {
+    nm_modality_t& md = j->mod[m];
+    if (md.Kx < 32 || md.D < 1) return -7;
+    for (int i = 0; i < NM_MAX_HID; ++i) { md.enc_s[i] = 0; md.dec_s[i] = 0; }
+    md.heads_s = 0;
+    if (m < Me) {
+      const int nch = (md.Kx + XCH - 1) / XCH;
+      md.enc_s[0] = o; o += (int64_t)nch * W0IMG_BYTES + VEC_BYTES;
+      for (int e = 1; e < j->L; ++e) { md.enc_s[e] = o; o += BLOB_BYTES; }
+      md.heads_s = o; o += BLOB_BYTES;
+    }
+    for (int d = 0; d < j->L; ++d) { md.dec_s[d] = o; o += BLOB_BYTES; }
+    md.out_s = o; o += (int64_t)((md.D + OCH - 1) / OCH) * OBLOB_BYTES;
+  }
+  return o;
+}
+
+int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
+  if (!jobs_dev) return -1;
+  if (n_jobs < 1) return -8;
+  hipLaunchKernelGGL(sync_shadow_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  return (int)hipGetLastError();
 }
 
 int64_t nm_workspace_bytes(const nm_job_t* j) {
@@ -2429,6 +2623,8 @@ static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int step
                        void* stream, bool scalar_tr) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1 || steps_per_tile < 1 || n_tiles < 1 || step0 < 0) return -8;
+  // concurrent tiles of one job share its parameters, moments and gradient buffer: forward-only
+  if (n_tiles > 1 && (flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return -8;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(n_jobs, n_tiles), block(WG);
   hipError_t e;
@@ -2508,16 +2704,22 @@ int nm_adam_step(float* params, const float* grads, float* m, float* v, int64_t 
   return (int)hipGetLastError();
 }
 
+int64_t nm_xb_elems(int rows_alloc, int Kx) {
+  if (rows_alloc < 1 || rows_alloc % NM_BATCH != 0 || Kx < 32 || Kx % 32 != 0) return -7;
+  return (int64_t)rows_alloc * ((Kx + XCH - 1) / XCH) * LDX;
+}
+
 int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx, uint16_t* xb,
-                  float* x_f32_out, int x_pitch, void* stream) {
+                  float* x_f32_out, int x_pitch, uint16_t* cz_out, int Cz, void* stream) {
   if (!x || !xb || (C > 0 && !c)) return -1;
   if (Kx % 32 != 0 || Kx < D + C + 1 || rows_alloc < n_rows || rows_alloc % NM_BATCH != 0) return -7;
   if (x_f32_out && (x_pitch % 4 != 0 || x_pitch < D || x_pitch > Kx)) return -7;
-  int64_t total = (int64_t)rows_alloc * Kx;
+  if (cz_out && (Cz % 8 != 0 || Cz < C + 1)) return -7;
+  int64_t total = nm_xb_elems(rows_alloc, Kx);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, c, n_rows, rows_alloc, D, C,
-                     Kx, xb, x_f32_out, x_pitch);
+                     Kx, xb, x_f32_out, x_pitch, cz_out, Cz);
   return (int)hipGetLastError();
 }
 

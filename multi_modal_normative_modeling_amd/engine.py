@@ -45,10 +45,14 @@ class Table:
     def __init__(self, x, c, device=None):
         dev = require_gpu(device)
         lib = _lib.load()
-        # content key of the covariates (shape, dtype, CRC of the bytes): tables with equal keys carry the same
-        # covariate block, which lets the decoders of a model share one z | c | 1 input (nm_job_t.shared_cov)
-        c_host = c.detach().cpu().contiguous().numpy() if torch.is_tensor(c) else np.ascontiguousarray(np.asarray(c))
-        self.c_key = (tuple(c_host.shape), str(c_host.dtype), zlib.crc32(c_host.tobytes()), zlib.adler32(c_host.tobytes()))
+        # content key of the covariates: tables with equal keys carry the same covariate block, which lets the
+        # decoders of a model share one z | c | 1 input (nm_job_t.shared_cov).  Host data: shape, dtype and two
+        # checksums of the bytes; device tensors: identity of the storage (no device-to-host copy, no sync)
+        if torch.is_tensor(c) and c.is_cuda:
+            self.c_key = ("dev", c.data_ptr(), tuple(c.shape), str(c.dtype), c._version)
+        else:
+            c_host = c.detach().contiguous().numpy() if torch.is_tensor(c) else np.ascontiguousarray(np.asarray(c))
+            self.c_key = (tuple(c_host.shape), str(c_host.dtype), zlib.crc32(c_host.tobytes()), zlib.adler32(c_host.tobytes()))
         x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
         c = torch.as_tensor(np.asarray(c) if not torch.is_tensor(c) else c)
         if x.dim() != 2 or c.dim() != 2 or x.shape[0] != c.shape[0]:
@@ -57,15 +61,24 @@ class Table:
         self.C = int(c.shape[1])
         self.rows_alloc = max(1, math.ceil(self.N / BATCH)) * BATCH
         self.Kx = (self.D + self.C + 1 + 31) // 32 * 32
+        self.Cz = (self.C + 1 + 7) // 8 * 8
         xs = x.to(device=dev, dtype=torch.float32).contiguous()
         cs = c.to(device=dev, dtype=torch.float32).contiguous()
         self.x_pitch = (self.D + 3) // 4 * 4
         self.x_f32 = torch.empty(self.rows_alloc, self.x_pitch, dtype=torch.float32, device=dev)
-        self.xb = torch.empty(self.rows_alloc, self.Kx, dtype=torch.bfloat16, device=dev)
+        # xb: 64-column chunk images of 256-row tiles, [tiles][chunks][256][72] (nm_modality_t.xb)
+        self.xb = torch.empty(int(lib.nm_xb_elems(self.rows_alloc, self.Kx)), dtype=torch.bfloat16, device=dev)
+        self.cz = torch.empty(self.rows_alloc, self.Cz, dtype=torch.bfloat16, device=dev)
         _lib.check(lib.nm_pack_table(xs.data_ptr(), cs.data_ptr() if self.C > 0 else None, self.N, self.rows_alloc,
                                      self.D, self.C, self.Kx, self.xb.data_ptr(), self.x_f32.data_ptr(),
-                                     self.x_pitch, _stream_ptr(dev)), "nm_pack_table")
+                                     self.x_pitch, self.cz.data_ptr(), self.Cz, _stream_ptr(dev)), "nm_pack_table")
         self.device = dev
+
+    def packed_rows(self) -> torch.Tensor:
+        """The packed operand rows x | c | 1 | 0 as a [rows_alloc, Kx] tensor (diagnostics / tests)."""
+        nch = (self.Kx + 63) // 64
+        t = self.xb.view(self.rows_alloc // BATCH, nch, BATCH, 72)[..., :64]
+        return t.permute(0, 2, 1, 3).reshape(self.rows_alloc, nch * 64)[:, :self.Kx]
 
     @property
     def n_tiles(self) -> int:
@@ -114,7 +127,7 @@ class Job:
         self.out_logits: Optional[torch.Tensor] = None
         self.cls_train, self.cls_use_mu = True, False
         self.cls_dropout, self.cls_margin, self.cls_w_ce, self.cls_w_contrast = 0.0, 1.0, 1.0, 0.1
-        self.dephase = os.environ.get("NMHIP_DEPHASE", "1") != "0"      # see nm_job_t.dephase
+        self.dephase_sleeps = 0          # set by JobSet (see nm_job_t.dephase)
         self.reg_lambda = 1.0                         # regression head (kind == "regression")
         self.fi_target: Optional[torch.Tensor] = None # [rows_alloc]
         self.out_fi_pred: Optional[torch.Tensor] = None
@@ -129,6 +142,8 @@ class Job:
         self._ws = None
         self._ws_tiles = 0
         self._version = 0                # bumped whenever the descriptor would change
+        self._wsh = None                 # bf16 shadow images of the weights (nm_job_t.wsh)
+        self.shadow_dirty = True         # params were written by the host: nm_sync_shadow before the next launch
         self._ensure_workspace(n_tiles_ws)
         # optional exports
         self.out_mu = self.out_logvar = self.out_z = None
@@ -146,9 +161,16 @@ class Job:
         probe.M, probe.L, probe.Z = len(self.kmods), len(self.spec.hidden), self.spec.latent
         probe.cls_layers, probe.cls_classes = len(self.spec.classifier_layers), (self.spec.num_classes if self.spec.classifier_layers else 0)
         probe.reg_head = 1 if self.spec.kind == "regression" else 0
+        probe.M_enc = self.spec.M
         for k, (m, _, _) in enumerate(self.kmods):
             probe.mod[k].D = self.tables[m].D
+            probe.mod[k].Kx = self.tables[m].Kx
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
+        if self._wsh is None:
+            nb = int(lib.nm_fill_shadow(C.byref(probe)))
+            if nb < 0:
+                _lib.check(nb, "nm_fill_shadow")
+            self._wsh = torch.zeros(nb, dtype=torch.uint8, device=self.device)
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
         self._version += 1
@@ -244,9 +266,7 @@ class Job:
         j.single_bypass = 1 if self.single_bypass else 0
         j.n_rows = self.tables[0].N
         j.non_linear = 1 if s.non_linear else 0
-        # one eighth of a train step in units of s_sleep(127) (~8128 cycles); a step costs ~5.3 cycles per parameter
-        # with the chip full (measured on 118 k .. 642 k parameter models)
-        j.dephase = int(round(self.layout.n_params * 5.3 / 8 / 8128)) if self.dephase else 0
+        j.dephase = int(self.dephase_sleeps)
         k0 = self.tables[0].c_key
         j.shared_cov = 1 if (k0 is not None and all(t.c_key == k0 for t in self.tables)) else 0
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
@@ -260,6 +280,7 @@ class Job:
         j.loss_log = self.loss_log.data_ptr()
         j.workspace = self._ws.data_ptr()
         j.workspace_stride = self.ws_bytes
+        j.wsh = self._wsh.data_ptr()
         j.out_mu = self.out_mu.data_ptr() if self.out_mu is not None else None
         j.out_logvar = self.out_logvar.data_ptr() if self.out_logvar is not None else None
         j.out_z = self.out_z.data_ptr() if self.out_z is not None else None
@@ -281,8 +302,8 @@ class Job:
         for k, (m, _, _) in enumerate(self.kmods):
             t = self.tables[m]
             md = j.mod[k]
-            md.D, md.Kx, md.x_pitch = t.D, t.Kx, t.x_pitch
-            md.x_f32, md.xb = t.x_f32.data_ptr(), t.xb.data_ptr()
+            md.D, md.Kx, md.x_pitch, md.Cz = t.D, t.Kx, t.x_pitch, t.Cz
+            md.x_f32, md.xb, md.cz = t.x_f32.data_ptr(), t.xb.data_ptr(), t.cz.data_ptr()
             self.layout.fill_modality(md, k)
             md.out_loc = self.out_loc[k].data_ptr() if self.out_loc[k] is not None else None
             md.out_sqerr = self.out_sqerr[k].data_ptr() if self.out_sqerr[k] is not None else None
@@ -290,6 +311,9 @@ class Job:
             md.dloc_extra = self.dloc_extra[k].data_ptr() if self.dloc_extra[k] is not None else None
             md.dloc_rowcoef = self.dloc_rowcoef[k].data_ptr() if self.dloc_rowcoef[k] is not None else None
             j.rowcoef_out[k] = md.dloc_rowcoef
+        nb = int(_lib.load().nm_fill_shadow(C.byref(j)))           # shadow-image offsets of every modality
+        if nb != self._wsh.numel():
+            raise _lib.NmError(f"shadow size changed: {nb} vs {self._wsh.numel()} bytes")
         _lib.check(_lib.load().nm_validate_job(C.byref(j)), "nm_validate_job")
         return j
 
@@ -299,6 +323,12 @@ class Job:
 
     def load_state_dict(self, state: Dict[str, torch.Tensor]):
         self.params.copy_(self.layout.flatten(state, device=self.device))
+        self.shadow_dirty = True
+
+    def params_changed(self):
+        """Call after writing ``params`` from the host side (an external optimizer, a hand edit): the bf16 shadow
+        images the kernels read are rebuilt before the next launch."""
+        self.shadow_dirty = True
 
     def grads_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().cpu().clone() for k, v in self.layout.unflatten(self.grads).items()}
@@ -325,9 +355,32 @@ class JobSet:
         self._dev = None
         self._sig = None
 
+    def _set_dephase(self):
+        """Start offsets of the jobs of a long launch (nm_job_t.dephase): workgroup b lands on XCD b mod 8 (observed
+        placement, speed only), so the 32 jobs that share an XCD -- its L2 and its link to memory -- are spread
+        evenly over one step, and the XCDs are staggered against each other by a fraction of that spacing.
+        NMHIP_DEPHASE = 0 switches it off, "xcd" is the round-1 scheme (one offset per XCD)."""
+        mode = os.environ.get("NMHIP_DEPHASE", "cu")
+        n = len(self.jobs)
+        for b, j in enumerate(self.jobs):
+            # ~4.8 shader cycles per parameter and step with the chip full (measured, 118 k .. 642 k parameters)
+            step_sleeps = j.layout.n_params * 4.8 / 8128
+            if mode == "0" or n < 16:
+                frac = 0.0
+            elif mode == "xcd":
+                frac = (b & 7) / 8
+            else:
+                per_xcd = max(1, (n + 7) // 8)
+                frac = ((b >> 3) + (b & 7) / 8) / per_xcd
+            s = int(round(step_sleeps * frac))
+            if s != j.dephase_sleeps:
+                j.dephase_sleeps = s
+                j._version += 1
+
     def _upload(self, n_tiles: int = 1):
         """Descriptor array on the device; rebuilt only when a job's descriptor changed (the
         optimizer step count rides on adam_off = t - step, constant while both advance)."""
+        self._set_dephase()
         for j in self.jobs:
             j._ensure_workspace(n_tiles)
         sig = tuple((j._version, j.t - j.step) for j in self.jobs)
@@ -336,6 +389,10 @@ class JobSet:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._dev = host.to(self.device)
             self._sig = sig
+        if any(j.shadow_dirty for j in self.jobs):
+            _lib.check(self.lib.nm_sync_shadow(self._dev.data_ptr(), len(self.jobs), _stream_ptr(self.device)), "nm_sync_shadow")
+            for j in self.jobs:
+                j.shadow_dirty = False
         return self._dev.data_ptr()
 
     def _launch(self, step0, steps_per_tile, n_tiles, flags, scalar_tr=False):

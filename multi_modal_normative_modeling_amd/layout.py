@@ -2,9 +2,12 @@
 
 Tensors keep the reference's ``state_dict`` names, shapes and order (cVAE.py:140-206,
 1087-1116), so ``load_state_dict``/``state_dict`` interchange weights with the reference.
-Inside the flat buffer every tensor starts on a 16-byte boundary and every weight matrix
-[N][K] is stored with its rows padded to a multiple of 8 floats (zeros), so each row is
-32-byte aligned: the kernels read weight fragments and sweep Adam with 16-byte accesses.
+Inside the kernel's flat buffer a weight matrix [N][K] is stored as 16 x 16 fp32 tiles,
+``[ceil(N/16)][ceil(K/16)][16][16]`` zero padded (1 KiB per tile, tile-aligned): the Adam sweep of
+the weight-gradient phase streams parameters and moments tile by tile, one lane-linear 16-byte
+access per lane.  Vectors (biases, logvar_out, alpha, BatchNorm tensors) are stored plain, 16-byte
+aligned.  ``flatten`` / ``unflatten`` convert between that buffer and the reference's tensors; the
+eager facade keeps a second, plain ("natural") buffer for parameter views (``nat_*``).
 """
 from __future__ import annotations
 
@@ -17,7 +20,7 @@ import torch
 from . import _lib
 
 ALIGN = 4   # floats
-ROW_PITCH = 8   # floats: weight-matrix rows are padded to this multiple (kpitch() in nmhip.hip)
+TILE = 16   # weight matrices are stored as TILE x TILE tiles (wt_off() in nmhip.hip)
 REGRESSOR_WIDTHS = (128, 64, 1)   # cVAE.py:2249-2253
 
 
@@ -157,36 +160,61 @@ class ParamLayout:
         self.spec = spec
         self.names: List[str] = []
         self.shapes: Dict[str, Tuple[int, ...]] = {}
-        self.offsets: Dict[str, int] = {}
-        self.pitch: Dict[str, int] = {}
-        off = 0
+        self.offsets: Dict[str, int] = {}          # kernel (tiled) buffer
+        self.tiles: Dict[str, Tuple[int, int]] = {}   # weight matrices: (row tiles, column tiles)
+        self.nat_offsets: Dict[str, int] = {}      # natural buffer: tensors row-major, back to back
+        off = nat = 0
         for name, shape in tensor_table(spec):
             self.names.append(name)
             self.shapes[name] = shape
-            self.offsets[name] = off
             if name.endswith(".weight") and len(shape) == 2:
-                self.pitch[name] = (shape[1] + ROW_PITCH - 1) // ROW_PITCH * ROW_PITCH
-                n = shape[0] * self.pitch[name]
+                off = (off + TILE * TILE - 1) // (TILE * TILE) * (TILE * TILE)
+                nt, kt = (shape[0] + TILE - 1) // TILE, (shape[1] + TILE - 1) // TILE
+                self.tiles[name] = (nt, kt)
+                n = nt * kt * TILE * TILE
             else:
                 n = math.prod(shape)
+            self.offsets[name] = off
             off += (n + ALIGN - 1) // ALIGN * ALIGN
+            self.nat_offsets[name] = nat
+            nat += (math.prod(shape) + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
+        self.nat_total = nat
         self.n_params = sum(math.prod(s) for s in self.shapes.values())
+        self._perm = None
 
     def numel(self, name: str) -> int:
         return math.prod(self.shapes[name])
 
-    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
-        """Strided view of one tensor inside the flat buffer (weights: padded row pitch)."""
+    # -- kernel (tiled) buffer ---------------------------------------------------------------------
+    def _tile_view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        """[NT, 16, KT, 16] view of a weight matrix inside the kernel buffer (element [a, r, b, c] = W[16a + r][16b + c])."""
+        nt, kt = self.tiles[name]
         o = self.offsets[name]
-        if name in self.pitch:
+        return flat[o:o + nt * kt * TILE * TILE].view(nt, kt, TILE, TILE).permute(0, 2, 1, 3)
+
+    def get(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        """One tensor out of the kernel buffer (weights: a copy; vectors: a view)."""
+        if name in self.tiles:
             n, k = self.shapes[name]
-            kp = self.pitch[name]
-            return flat[o:o + n * kp].view(n, kp)[:, :k]
+            nt, kt = self.tiles[name]
+            return self._tile_view(flat, name).reshape(nt * TILE, kt * TILE)[:n, :k]
+        o = self.offsets[name]
         return flat[o:o + self.numel(name)].view(self.shapes[name])
 
+    def put(self, flat: torch.Tensor, name: str, t: torch.Tensor):
+        t = t.to(dtype=torch.float32, device=flat.device)
+        if name in self.tiles:
+            n, k = self.shapes[name]
+            nt, kt = self.tiles[name]
+            pad = torch.zeros(nt * TILE, kt * TILE, dtype=torch.float32, device=flat.device)
+            pad[:n, :k] = t
+            self._tile_view(flat, name).copy_(pad.view(nt, TILE, kt, TILE))
+        else:
+            self.get(flat, name).copy_(t)
+
     def unflatten(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
-        return {n: self.view(flat, n) for n in self.names}
+        return {n: self.get(flat, n) for n in self.names}
 
     def flatten(self, state: Dict[str, torch.Tensor], device=None) -> torch.Tensor:
         flat = torch.zeros(self.total, dtype=torch.float32, device=device)
@@ -196,8 +224,45 @@ class ParamLayout:
             t = state[n]
             if tuple(t.shape) != tuple(self.shapes[n]):
                 raise ValueError(f"{n}: expected shape {self.shapes[n]}, got {tuple(t.shape)}")
-            self.view(flat, n).copy_(t.to(torch.float32))
+            self.put(flat, n, t)
         return flat
+
+    # -- natural buffer (eager facade: parameter VIEWS with the reference's names) -------------------
+    def nat_views(self, nat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {n: nat[self.nat_offsets[n]:self.nat_offsets[n] + self.numel(n)].view(self.shapes[n]) for n in self.names}
+
+    def nat_flatten(self, state: Dict[str, torch.Tensor], device=None) -> torch.Tensor:
+        nat = torch.zeros(self.nat_total, dtype=torch.float32, device=device)
+        for n, v in self.nat_views(nat).items():
+            if tuple(state[n].shape) != tuple(self.shapes[n]):
+                raise ValueError(f"{n}: expected shape {self.shapes[n]}, got {tuple(state[n].shape)}")
+            v.copy_(state[n].to(torch.float32))
+        return nat
+
+    def perm(self, device=None) -> torch.Tensor:
+        """perm[i] = position in the kernel buffer of element i of the natural buffer (-1 for alignment gaps)."""
+        if self._perm is None:
+            if self.total >= 1 << 24:
+                raise ValueError("model too large for the float index trick")
+            idx = torch.arange(self.total, dtype=torch.float32)       # exact below 2^24
+            nat = torch.full((self.nat_total,), -1.0)
+            for n, v in self.nat_views(nat).items():
+                v.copy_(self.get(idx, n))
+            self._perm = nat.to(torch.int64)
+        return self._perm if device is None else self._perm.to(device)
+
+    def nat_to_kernel(self, nat: torch.Tensor, out: torch.Tensor):
+        p = self.perm(nat.device)
+        ok = p >= 0
+        out.zero_()
+        out[p[ok]] = nat[ok]
+        return out
+
+    def kernel_to_nat(self, flat: torch.Tensor, out: torch.Tensor):
+        p = self.perm(flat.device)
+        ok = p >= 0
+        out[ok] = flat[p[ok]]
+        return out
 
     def init_reference_rule(self, seed: int = 42) -> Dict[str, torch.Tensor]:
         """nn.Linear default init U(+-1/sqrt(fan_in)) for weight and bias, logvar_out = -3,

@@ -45,6 +45,9 @@ def _probe(M=1, L=2, Z=10, C_=29, H=(110, 110), D=379):
         j.mod[m].D = D
         j.mod[m].Kx = (D + C_ + 1 + 31) // 32 * 32
         j.mod[m].x_pitch = (D + 3) // 4 * 4
+        j.mod[m].Cz = (C_ + 1 + 7) // 8 * 8
+    j.n_rows, j.loss_cap, j.eps_cap = 256, 1, 1
+    j.wsh = 4096           # any non-null address: validation does not dereference it
     return j
 
 
@@ -59,6 +62,32 @@ def test_validate_job_limits(lib):
     bad.mod[0].Kx = 400
     assert lib.nm_validate_job(C.byref(bad)) == -7
     assert b"Kx" in lib.nm_status_string(-7)
+    for field in ("n_rows", "loss_cap", "eps_cap"):            # modulo divisors inside the kernel
+        bad = _probe()
+        setattr(bad, field, 0)
+        assert lib.nm_validate_job(C.byref(bad)) == -14
+    bad = _probe()
+    bad.wsh = None
+    assert lib.nm_validate_job(C.byref(bad)) == -15
+    bad = _probe()
+    bad.mod[0].enc_w[0] = 8                                     # weight matrices start on a tile boundary
+    assert lib.nm_validate_job(C.byref(bad)) == -10
+
+
+def test_shadow_layout(lib):
+    j = _probe(M=3)
+    n = lib.nm_fill_shadow(C.byref(j))
+    assert n > 0 and n % 1024 == 0
+    offs = []
+    for m in range(3):
+        md = j.mod[m]
+        offs += [md.enc_s[0], md.enc_s[1], md.heads_s, md.dec_s[0], md.dec_s[1], md.out_s]
+    assert offs == sorted(offs) and len(set(offs)) == len(offs) and all(o % 1024 == 0 for o in offs)
+    # 7 chunk images [128][72] + 1 KiB of vectors for the first encoder layer of a 379 + 29 + 1 wide input
+    assert j.mod[0].enc_s[1] - j.mod[0].enc_s[0] == 7 * 128 * 72 * 2 + 1024
+    # 6 output chunk blobs of 18 KiB for 379 ROI
+    assert j.mod[1].enc_s[0] - j.mod[0].out_s == 6 * 18432
+    assert lib.nm_xb_elems(1024, 416) == 1024 * 7 * 72
 
 
 def test_workspace_bytes(lib):
@@ -79,12 +108,19 @@ def test_param_layout_matches_reference_names():
             assert tuple(v.shape) == tuple(w[k].shape)
             assert (v == w[k]).all()
         assert all(o % 4 == 0 for o in lay.offsets.values())
-        assert all(v % 8 == 0 for v in lay.pitch.values())
-        # pad columns of every weight row stay zero
-        for k, kp in lay.pitch.items():
+        # weight matrices: whole 16 x 16 tiles on tile boundaries, zero outside the matrix
+        for k, (nt, kt) in lay.tiles.items():
             n, kk = lay.shapes[k]
             o = lay.offsets[k]
-            assert (flat[o:o + n * kp].view(n, kp)[:, kk:] == 0).all()
+            assert o % 256 == 0
+            full = flat[o:o + nt * kt * 256].view(nt, kt, 16, 16).permute(0, 2, 1, 3).reshape(nt * 16, kt * 16)
+            assert (full[:n, :kk] == w[k]).all() and (full[n:] == 0).all() and (full[:, kk:] == 0).all()
+            assert float(flat[o + 16 * 1 + 3]) == float(w[k][1, 3])          # wt_off(1, 3) inside tile (0, 0)
+        # natural <-> kernel buffer (the eager facade's parameter views)
+        nat = lay.nat_flatten(w)
+        import torch
+        assert torch.equal(lay.nat_to_kernel(nat, torch.zeros(lay.total)), flat)
+        assert torch.equal(lay.kernel_to_nat(flat, torch.zeros(lay.nat_total)), nat)
     g = Golden("cfgA_T1w")
     assert nm.ParamLayout(nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim)).n_params == 118479
 

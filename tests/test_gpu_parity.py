@@ -51,11 +51,11 @@ def test_gemm_forms(mode):
         A = bf(torch.randn(M, N, generator=g)); B = bf(torch.randn(M, K, generator=g))
         ref = A.T @ B
         out = torch.zeros(N, K, device=DEV)
-    if mode in (0, 1):                    # weight operand in the flat-buffer format: rows padded to 8 floats
-        kp = (B.shape[1] + 7) // 8 * 8
-        Bp = torch.zeros(B.shape[0], kp)
-        Bp[:, :B.shape[1]] = B
-        B = Bp
+    if mode in (0, 1):                    # weight operand in the flat-buffer format: 16 x 16 tiles, zero padded
+        nt, kt = (B.shape[0] + 15) // 16, (B.shape[1] + 15) // 16
+        Bp = torch.zeros(nt * 16, kt * 16)
+        Bp[:B.shape[0], :B.shape[1]] = B
+        B = Bp.view(nt, 16, kt, 16).permute(0, 2, 1, 3).contiguous()
     Ad, Bd = A.to(DEV).contiguous(), B.to(DEV).contiguous()
     _lib.check(lib.nm_test_gemm(mode, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), M, N, K, st))
     torch.cuda.synchronize()

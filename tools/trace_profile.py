@@ -6,13 +6,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 import multi_modal_normative_modeling_amd as nm
 from multi_modal_normative_modeling_amd import prep, workload, _lib
-TAGS = {0: "FL issue w", 1: "FL wait+mfma", 2: "FL barrier1", 3: "FL epilogue", 4: "FL barrier2", 5: "FL store_act",
-        6: "F0 prologue", 7: "F0 xstore", 8: "F0 barrier a", 9: "F0 issue next", 10: "F0 mfma+cvt next", 11: "F0 barrier b", 12: "F0 epi",
-        13: "HD compute", 14: "HD full barrier", 15: "LAT loop", 22: "LAT blocksum", 23: "ZC build", 24: "ZC barrier+save",
-        16: "XC prev->top", 17: "XC zero+barrier", 18: "XC issue loads", 19: "XC wait+mfma", 20: "XC epilogue", 21: "XC barrier",
-        33: "DG entry(gap)", 34: "DG compute", 35: "DG barrier", 26: "WG request", 27: "WG tiles", 28: "WG barrier", 29: "WG sweep",
-        30: "WG barrier2", 31: "DB gap", 32: "DB load_act", 36: "DB barrier", 37: "EB prep", 38: "EB load_act", 39: "EB barrier",
-        40: "L0W gap", 41: "L0W xstore", 42: "L0W barrier", 43: "BW gap", 44: "BW finish_delta", 45: "BW barrier", 62: "tail", 63: "step barrier"}
+TAGS = {0: "enc L0 fwd", 1: "enc hidden fwd", 2: "enc heads", 3: "latent + KL", 4: "zc build", 5: "dec hidden fwd",
+        6: "out: wait+x req+mfma", 7: "out: epilogue", 8: "out: dlv + dgrad", 9: "out: wgrad+adam", 10: "dec bwd dgrad+act",
+        11: "dec bwd wgrad+adam", 12: "dz + fusion bwd", 13: "enc bwd heads dgrad+act", 14: "enc bwd heads/hidden wgrad+...",
+        15: "enc L0 wgrad+adam", 62: "tail", 63: "step barrier"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--steps", type=int, default=16)
