@@ -10,14 +10,22 @@ the 3-modality SE-gPoE cVAE_multimodal (3 x 379 ROI, batch 256, c = 29, H = [110
 `--jobs` independent models per GPU (fold = job mod 5), one persistent workgroup each.  A bench
 "step" advances EVERY job by one train step (forward + ELBO + backward + Adam on its next 256-row
 batch); value = job-steps per second over all GPUs.  Ranks share nothing on the data path (weak
-scaling); RCCL carries only the barrier and the max-over-ranks of the elapsed time.
+scaling); RCCL carries the barriers, the max-over-ranks of the elapsed time and, at the end, the
+sweep's one collective: the all_gather of the per-model metric table (sweep.gather_metrics).
+
+Timing: W warm-up steps, then further untimed launches until at least --min-warm-s seconds of work
+have run (clocks and caches settled), then the K-step region is timed `--repeats` times, each
+bracketed by barrier + synchronize; `value` / `ms_per_step` come from the MEDIAN region, min / max
+are reported beside it.
 
 Inputs are synthetic, resident in HBM before the timed region.  The CPU leg
 times the oracle (a PyTorch-CPU port of the same step, oracle/) on the host cores, rank 0 only.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -26,11 +34,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 
+def kernel_src_sha16() -> str:
+    """Identity of the kernel source the loaded library was built from (bench <-> PMC record match)."""
+    h = hashlib.sha256()
+    for p in (ROOT / "multi_modal_normative_modeling_amd" / "csrc" / "nmhip.hip", ROOT / "include" / "nmhip.h"):
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--repeats", type=int, default=9, help="times the K-step region is timed (median reported)")
+    ap.add_argument("--min-warm-s", type=float, default=0.5, help="untimed work before the first timed region")
     ap.add_argument("--jobs", type=int, default=256, help="independent models per GPU (one workgroup each)")
     ap.add_argument("--procedure", default="SE-gPoE", help="SM-<modality> | SE-<combine> | UCA-<combine>")
     ap.add_argument("--steps-per-launch", type=int, default=128,
@@ -45,7 +63,7 @@ def main():
     T0 = time.perf_counter()
     import torch
     import multi_modal_normative_modeling_amd as nm
-    from multi_modal_normative_modeling_amd import prep, workload
+    from multi_modal_normative_modeling_amd import prep, sweep, workload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,25 +118,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- warm-up: W steps, then whole K-step regions until min_warm_s of work has run ----
     run_steps(args.warmup)
     barrier()
-    log("warmup done")
-    events = []
-    t0 = time.perf_counter()
-    run_steps(args.steps, events)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    warm_extra, tw = 0, time.perf_counter()
+    while time.perf_counter() - tw < args.min_warm_s:
+        run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        warm_extra += args.steps
     barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    log(f"warmup done ({args.warmup} + {warm_extra} steps)")
 
-    log(f"timed region done: {elapsed:.3f}s")
+    # ---- timed: the K-step region, `repeats` times, each bracketed by barrier + synchronize ----
+    events, regions = [], []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps, events)
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        regions.append(elapsed)
+    elapsed = statistics.median(regions)
+    log(f"timed regions: median {elapsed * 1e3:.2f} ms, min {min(regions) * 1e3:.2f}, max {max(regions) * 1e3:.2f} "
+        f"({len(regions)} x {args.steps} steps)")
     # sanity: training really happened and stayed finite
-    losses = jobs[0].loss_log.cpu()
-    if not torch.isfinite(losses).all():
-        raise SystemExit("non-finite loss in the bench run")
+    js.assert_finite()
 
     # ---- roofline of the dominant kernel (nm_step_kernel), from HIP events on its own stream ----
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
@@ -128,21 +157,25 @@ def main():
     bytes_per_launch = work["bytes"] * args.jobs * steps_per_launch          # algorithmic, SURVEY 8(d)
     flop_per_launch = work["flop"] * args.jobs * steps_per_launch
     hbm_gbs = bytes_per_launch / avg_launch_s / 1e9
-    # HBM traffic from the committed rocprofv3 PMC passes of this same command (profiles/): FETCH_SIZE and
-    # WRITE_SIZE in separate passes, KB -> bytes, FETCH doubled per the gfx950 correction.  null when the
-    # committed measurement is for a different workload.
-    traffic = None
+    # HBM traffic: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over this same command
+    # (tools/run_pmc.sh -> profiles/pmc_hbm_traffic.json; KB -> bytes, FETCH doubled per the gfx950 correction),
+    # used ONLY when the record was taken on this very kernel source and workload; otherwise null.
+    traffic, traffic_src = None, None
     pmc = ROOT / "profiles" / "pmc_hbm_traffic.json"
     if pmc.exists():
         rec = json.loads(pmc.read_text())
-        if rec.get("procedure") == args.procedure and rec.get("jobs") == args.jobs:
+        if (rec.get("kernel_src_sha16") == kernel_src_sha16() and rec.get("procedure") == args.procedure
+                and rec.get("jobs") == args.jobs):
             traffic = rec["hbm_bytes_per_job_step_corrected"] * args.jobs * steps_per_launch
+            traffic_src = (f"profiles/pmc_hbm_traffic.json ({rec.get('tag', '?')}: FETCH x2 + WRITE, "
+                           f"{rec.get('steps_per_launch')} steps/launch)")
     roofline = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(hbm_gbs / 8000.0, 5), "traffic": traffic,
-                "kernel": "nm_step_kernel", "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "frac": round(hbm_gbs / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "nm_step_kernel", "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches_timed": launches,
                 "algorithmic_bytes_per_job_step": work["bytes"],
                 "mfma_bf16_tflops": round(flop_per_launch / avg_launch_s / 1e12, 3),
-                "mfma_frac_of_2500": round(flop_per_launch / avg_launch_s / 2.5e15, 5)}
+                "mfma_frac_of_2500": round(flop_per_launch / avg_launch_s / 2.5e15, 5),
+                "kernel_src_sha16": kernel_src_sha16()}
 
     total_job_steps = args.jobs * args.steps * world
     value = total_job_steps / elapsed
@@ -151,6 +184,8 @@ def main():
         "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "repeats": len(regions), "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+        "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4), "warmup_extra_steps": warm_extra,
         "config": {"workload": f"{args.procedure} cVAE_multimodal sweep: {len(spec.input_dims)} x 379 ROI, batch 256, "
                                f"c=29, H=[110,110], Z=10, 5 folds x replicas, {args.jobs} independent models per GPU, "
                                f"in-kernel reparameterisation draw",
@@ -158,6 +193,21 @@ def main():
                    "train_rows_per_model": jobs[0].tables[0].N, "parallelism": f"sweep-sharded x{world}"},
         "roofline": roofline,
     }
+
+    # ---- the sweep's one collective, on the real payload: per-model metric rows, all_gather over the ranks ----
+    nan = float("nan")
+    tdev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")
+    local = torch.full((len(jobs), sweep.N_METRICS), nan, dtype=torch.float32, device=tdev)
+    local[:, 0] = torch.arange(rank * args.jobs, rank * args.jobs + len(jobs), dtype=torch.float32, device=tdev)
+    local[:, 1] = torch.arange(len(jobs), device=tdev) % 5
+    local[:, 2] = 0.0
+    local[:, 3] = torch.stack([j.loss_log[(j.step - 1) % j.loss_cap, 0] for j in jobs]).to(tdev)   # final total loss
+    local[:, 4] = value / world / max(1, args.jobs)
+    table = sweep.gather_metrics(local, args.jobs)
+    if rank == 0:
+        if table.shape[0] != args.jobs * world or not torch.isfinite(table[:, 3]).all():
+            raise SystemExit(f"metric gather: {tuple(table.shape)} rows, finite={bool(torch.isfinite(table[:, 3]).all())}")
+        out["config"]["metric_table_rows_gathered"] = int(table.shape[0])
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N = 1 only) ----
     if world == 1 and args.cpu_budget > 0:

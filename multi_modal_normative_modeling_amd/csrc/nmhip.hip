@@ -352,6 +352,19 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 #ifndef NM_NT_STREAM
 #define NM_NT_STREAM 0
 #endif
+// Requesting the p / m / v of a weight-gradient phase's first units one or more phases ahead (output chunks: before the
+// GEMM / after the epilogue; hidden layers: before the dgrad; first encoder layer: a whole pass ahead).  Measured
+// (round 2, 256 SE-gPoE models): every variant costs registers the step does not have -- 18 to 227 VGPR spills --
+// and is 0 % (hidden) to 13 % (output chunks, first layer) SLOWER.  Kept as compile-time experiments, off.
+#ifndef NM_PRE_OUT
+#define NM_PRE_OUT 0
+#endif
+#ifndef NM_PRE_HID
+#define NM_PRE_HID 0
+#endif
+#ifndef NM_PRE_L0
+#define NM_PRE_L0 0
+#endif
 // POL = 2: streaming (nt) -- for bytes this workgroup alone reads, once per step (weight images, saved activations);
 // the ROI tables, which the models of a fold share through L2 / Infinity Cache, keep the default policy.
 template <int POL = 0>
@@ -568,14 +581,18 @@ __device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT]
 // bias gradient), columns (N, wpad(N)) := 0.  The layer's weight image [128][LDP] and bias vector were requested
 // by the PREVIOUS phase into half `half` of Q / vector slot `half`; this phase first requests `nx` (the next
 // phase's image), then waits for its own.  Optionally saved to `save` (activation image) for the backward pass.
-__device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& nx, int N, int K, bool act, gbf16 save) {
+// `younger` = vector-memory operations this wave issued AFTER the request of this layer's image and before this call
+// (the previous phase's activation save: ACT_STORES): they may stay in flight.
+constexpr int ACT_STORES = (ROWS * 16) / WG;
+__device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& nx, int N, int K, bool act, gbf16 save,
+                                          int younger) {
   Ctx c = cc;
   relaunder(c);
   const int ksteps = wpad(K) / 32;       // <= 4
   const int ntn = wpad(N) / 16;
   const __bf16* Wt = c.Q + half * (IMG_ROWS * LDP);
   const int n_next = issue_next(c, nx);
-  wait_vm(n_next);
+  wait_vm(n_next + younger);
   lds_barrier();
   f32x4 acc[2][RT];
   zero_acc(acc);
@@ -663,7 +680,7 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality
 // Heads image: rows [0, Z) = enc_mean_layer, rows [Zs, Zs + Z) = enc_logvar_layer, zeros elsewhere; the vector
 // piece holds the biases at the same row indices.
 __device__ __forceinline__ void fwd_heads(const Ctx& cc, int half, const Next& nx, int Z, int K, gf32 mu_out, gf32 lv_out,
-                                          int Zs) {
+                                          int Zs, int younger) {
   Ctx c = cc;
   relaunder(c);
   const int ksteps = wpad(K) / 32;
@@ -671,7 +688,7 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, int half, const Next& n
   const __bf16* Wt = c.Q + half * (IMG_ROWS * LDP);
   const float* bias = c.vec + half * (VEC_BYTES / 4);
   const int n_next = issue_next(c, nx);
-  wait_vm(n_next);
+  wait_vm(n_next + younger);
   lds_barrier();
   // unit = (feature tile, row tile of the wave's row half): the 4 waves of a row half share them round-robin,
   // so all 8 waves work even when the latent fits one feature tile
@@ -813,22 +830,60 @@ struct WgT {
   GAS float* sh_b;    // fp32 bias copy that travels with the image (row 0); nullptr: none
   float* patch;       // LDS, NWAVES * PATCH_FLOATS floats
 };
+struct WgGeom { int N, K, k_base, ncols; WgT T; };
 struct PMV { f32x4 p[2], m[2], v[2]; float bp, bm, bv; };
+__device__ __forceinline__ int wg_units(const WgGeom& G) { return ((G.N + 15) >> 4) * ((((G.ncols + 15) >> 4) + 1) >> 1); }
+__device__ __forceinline__ int wg_bias_pair(const WgGeom& G) {
+  const bool has_bias = (G.T.b_off >= 0) && (G.K >= G.k_base) && (G.K < G.k_base + G.ncols);
+  return has_bias ? ((G.K - G.k_base) >> 5) : -1;
+}
+// Request p / m / v of unit u (wave-uniform) of geometry G: the master keeps every 16 x 16 tile as 1 KiB of
+// contiguous memory, so each request is one lane-linear 16-byte load per lane (full lines, streaming).
+__device__ __forceinline__ void wg_request(const Ctx& c, const WgGeom& G, int u, PMV& s) {
+  const nm_job_t* J = c.job;
+  gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
+  const int KT = ktiles(G.K), kt0 = G.k_base >> 4;
+  const int nktp = (G.ncols + 15) >> 4, nkp = (nktp + 1) >> 1;
+  const int nt = u / nkp, kp = u - nt * nkp;            // wave-uniform: scalar division
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ktl = 2 * kp + j;
+    s.p[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s.m[j] = s.p[j]; s.v[j] = s.p[j];
+    if (ktl < nktp && kt0 + ktl < KT) {
+      const int64_t idx = G.T.w_off + ((int64_t)(nt * KT + kt0 + ktl) << 8) + c.lane * 4;
+#if NM_NT_STREAM
+      s.p[j] = __builtin_nontemporal_load((const GAS f32x4*)(Pp + idx));
+#else
+      s.p[j] = *(const GAS f32x4*)(Pp + idx);
+#endif
+      // the moments are touched once per step: streaming (nt) accesses keep them from evicting what is re-read
+      s.m[j] = __builtin_nontemporal_load((const GAS f32x4*)(Mp + idx));
+      s.v[j] = __builtin_nontemporal_load((const GAS f32x4*)(Vp + idx));
+    }
+  }
+  s.bp = 0.f; s.bm = 0.f; s.bv = 0.f;
+  if (kp == wg_bias_pair(G)) {
+    const int64_t bidx = G.T.b_off + min(nt * 16 + (c.lane >> 2), G.N - 1);
+    s.bp = Pp[bidx]; s.bm = Mp[bidx]; s.bv = Vp[bidx];
+  }
+}
 
+// pre0 / pre1: p / m / v of this wave's first / second unit (units wave, wave + 8), requested by the caller phases
+// ahead (nullptr: requested here).
 template <bool SCALAR_TR>
 __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
-                                           int N, int K, int k_base, int ncols, const WgT& T) {
+                                           const WgGeom& G, const PMV* pre0 = nullptr, const PMV* pre1 = nullptr) {
   Ctx c = cc;
   relaunder(c);
   const nm_job_t* J = c.job;
+  const WgT& T = G.T;
+  const int N = G.N, K = G.K, k_base = G.k_base, ncols = G.ncols;
   const int KT = ktiles(K), kt0 = k_base >> 4;
-  const int nnt = (N + 15) >> 4;                // n tiles
   const int nktp = (ncols + 15) >> 4;           // k tiles of this pass
   const int nkp = (nktp + 1) >> 1;              // pairs
-  const int nunits = nnt * nkp;
-  const bool has_bias = (T.b_off >= 0) && (K >= k_base) && (K < k_base + ncols);
+  const int nunits = wg_units(G);
   const int kb = K - k_base;                    // pass column of the ones column
-  const int kb_pair = has_bias ? (kb >> 5) : -1, kb_j = (kb >> 4) & 1, kb_col = kb & 15;
+  const int kb_pair = wg_bias_pair(G), kb_j = (kb >> 4) & 1, kb_col = kb & 15;
   const bool do_adam = (c.flags & NM_F_ADAM) != 0;
   const bool do_grads = (c.flags & NM_F_GRADS) != 0;
   const AdamK ak = adam_consts(c);
@@ -836,37 +891,17 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
   float* patch = T.patch + c.wave * PATCH_FLOATS;
   const int prow = c.lane >> 2, pcol = (c.lane & 3) * 4;          // this lane's element group inside a tile
 
-  auto request = [&](int u, PMV& s) {
-    const int nt = u / nkp, kp = u - nt * nkp;            // wave-uniform: scalar division
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ktl = 2 * kp + j;
-      s.p[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s.m[j] = s.p[j]; s.v[j] = s.p[j];
-      if (ktl < nktp && kt0 + ktl < KT) {
-        const int64_t idx = T.w_off + ((int64_t)(nt * KT + kt0 + ktl) << 8) + c.lane * 4;
-#if NM_NT_STREAM
-        s.p[j] = __builtin_nontemporal_load((const GAS f32x4*)(Pp + idx));
-#else
-        s.p[j] = *(const GAS f32x4*)(Pp + idx);
-#endif
-        // the moments are touched once per step: streaming (nt) accesses keep them from evicting what is re-read
-        s.m[j] = __builtin_nontemporal_load((const GAS f32x4*)(Mp + idx));
-        s.v[j] = __builtin_nontemporal_load((const GAS f32x4*)(Vp + idx));
-      }
-    }
-    s.bp = 0.f; s.bm = 0.f; s.bv = 0.f;
-    if (kp == kb_pair) {
-      const int64_t bidx = T.b_off + min(nt * 16 + prow, N - 1);
-      s.bp = Pp[bidx]; s.bm = Mp[bidx]; s.bv = Vp[bidx];
-    }
-  };
-
   PMV cur, nxt;
   int u = c.wave;
-  if (do_adam && u < nunits) request(u, cur);
+  bool have_nxt = false;
+  if (do_adam && u < nunits) {
+    if (pre0) cur = *pre0; else wg_request(c, G, u, cur);
+    if (pre1 && u + NWAVES < nunits) { nxt = *pre1; have_nxt = true; }
+  }
   while (u < nunits) {
     const int un = u + NWAVES;
-    if (do_adam && un < nunits) request(un, nxt);
+    if (do_adam && !have_nxt && un < nunits) wg_request(c, G, un, nxt);
+    have_nxt = false;
     const int nt = u / nkp, kp = u - nt * nkp;
     // ---- MFMAs: acc[j] = k tile 2 kp + j of n tile nt ----
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1104,12 +1139,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     for (int e = 1; e < L; ++e) {
       gbf16 sv = bwd ? (gbf16)(ws_enc + (int64_t)(m * L + e) * ACT_BYTES) : (gbf16)nullptr;
       const GAS char* nxt = wsh + (e + 1 < L ? md.enc_s[e + 1] : md.heads_s);
-      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1), J->H[e], J->H[e - 1], nl, sv);
+      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1), J->H[e], J->H[e - 1], nl, sv, bwd ? ACT_STORES : 0);
       half ^= 1;
     }
     tr(c, 1);
     prof(c, PH_ENC_REST);
-    fwd_heads(c, half, no_next(), Z, J->H[L - 1], ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs);
+    fwd_heads(c, half, no_next(), Z, J->H[L - 1], ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs,
+              bwd ? ACT_STORES : 0);
     prof(c, PH_HEADS);
   }
 
@@ -1187,7 +1223,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       gbf16 sv = (bwd && d < L - 1) ? (gbf16)(ws_dec + (int64_t)d * ACT_BYTES) : (gbf16)nullptr;
       Next nx = (d + 1 < L) ? blob_to_half(c, wsh + md.dec_s[d + 1], half ^ 1)
                             : Next{oblob, Sb, OBLOB_BYTES >> 10, nullptr, nullptr};
-      fwd_layer(c, half, nx, Nout, Kin, nl, sv);
+      // (d == 0: the z | c | 1 build / reload sits between the image request and here -- wait for everything)
+      fwd_layer(c, half, nx, Nout, Kin, nl, sv, (d > 0 && bwd) ? ACT_STORES : 0);
       half ^= 1;
     }
     tr(c, 5);
@@ -1219,8 +1256,18 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       char* const other = (ch & 1) ? Sb : slotA;
       const __bf16* Wc = reinterpret_cast<const __bf16*>(slot);
       const float* vb = reinterpret_cast<const float*>(slot + OIMG_BYTES);      // bias[64], then logvar_out[64]
+      // this chunk's weight-gradient target; p / m / v of this wave's two units are requested well ahead of the
+      // weight-gradient phase: the first right below (in flight during the GEMM and the epilogue), the second
+      // after the epilogue
+      GAS char* const oimg = wsh + md.out_s + (int64_t)ch * OBLOB_BYTES;
+      const WgGeom Go{valid, Hl, 0, rup(Hl + 1, 16),
+                      WgT{md.out_w + (int64_t)(d0 >> 4) * KTo * 256, md.out_b + d0, oimg, LDP * 2, (GAS float*)(oimg + OIMG_BYTES), opatch}};
+      const bool adam_on = bwd && (c.flags & NM_F_ADAM);
+      PMV pm_a, pm_b;
       if (c.tid < OCH) c.colacc[c.tid] = 0.f;
-      wait_vm(0);                                 // chunk ch's blob (requested a chunk ago) and everything older
+      // chunk ch's blob (requested a chunk ago) and everything older; from the second chunk on at least the RT
+      // fp32 input loads of the previous chunk are younger than it and may stay in flight (with Adam: its last stores)
+      wait_vm(ch > 0 ? RT : 0);
       lds_barrier();                              // ... for every wave; also: the previous chunk is finished everywhere
       if (ch + 1 < nck) dma_lin(c, oblob + (int64_t)(ch + 1) * OBLOB_BYTES, other, OBLOB_BYTES >> 10);
       // fp32 inputs of the residual (rows are always inside the zero-padded table): in flight during the MFMAs
@@ -1233,6 +1280,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         for (int rt = 0; rt < RT; ++rt)
           xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
       }
+#if NM_PRE_OUT == 2
+      if (adam_on && c.wave < wg_units(Go)) wg_request(c, Go, c.wave, pm_a);
+#endif
       // x_hat chunk: acc[rt] = features dl0..dl0+3 of row (wm, rt, c16)
       f32x4 acc[RT];
 #pragma unroll
@@ -1335,6 +1385,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       if (!bwd) continue;                         // forward only: the next chunk's barrier protects the slots
       lds_barrier();                              // delta chunk and column sums complete
       relaunder(c);
+#if NM_PRE_OUT == 1
+      if (adam_on && c.wave < wg_units(Go)) wg_request(c, Go, c.wave, pm_a);
+#endif
+#if NM_PRE_OUT >= 1
+      if (adam_on && c.wave + NWAVES < wg_units(Go)) wg_request(c, Go, c.wave + NWAVES, pm_b);
+#endif
       // d logvar_out for this chunk (master + the copy that travels with the chunk's image)
       if (c.tid < valid)
         apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b,
@@ -1344,11 +1400,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       tr(c, 8);
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Dq[r][d] P[r][k]
-      {
-        GAS char* img = wsh + md.out_s + (int64_t)ch * OBLOB_BYTES;
-        WgT T{md.out_w + (int64_t)(d0 >> 4) * KTo * 256, md.out_b + d0, img, LDP * 2, (GAS float*)(img + OIMG_BYTES), opatch};
-        wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, valid, Hl, 0, rup(Hl + 1, 16), T);
-      }
+#if NM_PRE_OUT >= 1
+      wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, Go, adam_on ? &pm_a : nullptr, adam_on ? &pm_b : nullptr);
+#else
+      wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, Go);
+#endif
       tr(c, 9);
       prof(c, PH_OUT_WGRAD);
     }
@@ -1377,14 +1433,16 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       f32x4 acc[2][RT];
       zero_acc(acc);
       const GAS char* act_img = d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ACT_BYTES;
-      dgrad_hidden(c, acc, wsh + md.dec_s[d], act_img, Nout);
+      GAS char* const dimg = wsh + md.dec_s[d];
+      const WgGeom Gd{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.dec_w[d], md.dec_b[d], dimg, LDP * 2, (GAS float*)(dimg + IMG_BYTES), spatch}};
+      PMV pm_d;                                   // first unit's p / m / v: in flight during the dgrad and the reloads
+#if NM_PRE_HID
+      if ((c.flags & NM_F_ADAM) && c.wave < wg_units(Gd)) wg_request(c, Gd, c.wave, pm_d);
+#endif
+      dgrad_hidden(c, acc, dimg, act_img, Nout);
       tr(c, 10);
       prof(c, PH_DEC_DGRAD);
-      {
-        GAS char* img = wsh + md.dec_s[d];
-        WgT T{md.dec_w[d], md.dec_b[d], img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch};
-        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), T);
-      }
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gd, (NM_PRE_HID && (c.flags & NM_F_ADAM)) ? &pm_d : nullptr);
       tr(c, 11);
       prof(c, PH_DEC_WGRAD);
       if (d > 0) {
@@ -1540,10 +1598,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     tr(c, 13);
     {
       GAS char* img = wsh + md.heads_s;
-      WgT Tm{md.mu_w, md.mu_b, img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch};
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), Tm);
-      WgT Tl{md.lv_w, md.lv_b, img + (int64_t)Zs * LDP * 2, LDP * 2, (GAS float*)(img + IMG_BYTES) + Zs, spatch};
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Z, Hh, 0, rup(Hh + 1, 16), Tl);
+      const WgGeom Gm{Z, Hh, 0, rup(Hh + 1, 16), WgT{md.mu_w, md.mu_b, img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch}};
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gm);
+      const WgGeom Gl{Z, Hh, 0, rup(Hh + 1, 16),
+                      WgT{md.lv_w, md.lv_b, img + (int64_t)Zs * LDP * 2, LDP * 2, (GAS float*)(img + IMG_BYTES) + Zs, spatch}};
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Gl);
     }
     prof(c, PH_ENCB_HEADS_WGRAD);
     finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
@@ -1552,13 +1611,15 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     for (int e = L - 1; e >= 1; --e) {
       int Kin = J->H[e - 1], Nout = J->H[e];
       zero_acc(acc);
-      dgrad_hidden(c, acc, wsh + md.enc_s[e], ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout);
+      GAS char* const eimg = wsh + md.enc_s[e];
+      const WgGeom Ge{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.enc_w[e], md.enc_b[e], eimg, LDP * 2, (GAS float*)(eimg + IMG_BYTES), spatch}};
+      PMV pm_e;
+#if NM_PRE_HID
+      if ((c.flags & NM_F_ADAM) && c.wave < wg_units(Ge)) wg_request(c, Ge, c.wave, pm_e);
+#endif
+      dgrad_hidden(c, acc, eimg, ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout);
       prof(c, PH_ENCB_DGRAD);
-      {
-        GAS char* img = wsh + md.enc_s[e];
-        WgT T{md.enc_w[e], md.enc_b[e], img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch};
-        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Nout, Kin, 0, rup(Kin + 1, 16), T);
-      }
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Ge, (NM_PRE_HID && (c.flags & NM_F_ADAM)) ? &pm_e : nullptr);
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
       lds_barrier();
@@ -1573,15 +1634,40 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const GAS char* xsrc = (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * nch * XIMG_BYTES;
       GAS char* img = wsh + md.enc_s[0];
       dma_lin<0>(c, xsrc, Qb, XIMG_BYTES >> 10);
-      for (int kc = 0; kc < nch; ++kc) {
+      const bool adam_on = NM_PRE_L0 && (c.flags & NM_F_ADAM) != 0;
+      auto geom = [&](int kc) {
+        return WgGeom{N0, K0, kc * XCH, min(XCH, Kx - kc * XCH),
+                      WgT{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * W0IMG_BYTES, LDX * 2,
+                          (GAS float*)(img + (int64_t)nch * W0IMG_BYTES), spatch}};
+      };
+      // p / m / v of pass kc + 1 (both units of this wave) are requested at the start of pass kc: two register sets
+      // that swap roles from pass to pass (the loop is unrolled by two so that the sets keep their names)
+      PMV ea0, ea1, eb0, eb1;
+      auto request_pass = [&](int kc, PMV& s0, PMV& s1) {
+        if (!adam_on || kc >= nch) return;
+        const WgGeom Gn = geom(kc);
+        if (c.wave < wg_units(Gn)) wg_request(c, Gn, c.wave, s0);
+        if (c.wave + NWAVES < wg_units(Gn)) wg_request(c, Gn, c.wave + NWAVES, s1);
+      };
+      request_pass(0, ea0, ea1);
+      for (int kc = 0; kc < nch; kc += 2) {
         wait_vm(0);
         lds_barrier();                            // chunk kc has landed everywhere; chunk kc - 1 is finished everywhere
         if (kc + 1 < nch) dma_lin<0>(c, xsrc + (int64_t)(kc + 1) * XIMG_BYTES, Qb + ((kc + 1) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
-        const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + (kc & 1) * XIMG_BYTES);
-        int cols = min(XCH, Kx - kc * XCH);
-        WgT T{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * W0IMG_BYTES, LDX * 2,
-              (GAS float*)(img + (int64_t)nch * W0IMG_BYTES), spatch};
-        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, N0, K0, kc * XCH, cols, T);
+        request_pass(kc + 1, eb0, eb1);
+        {
+          const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + (kc & 1) * XIMG_BYTES);
+          wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc), adam_on ? &ea0 : nullptr, adam_on ? &ea1 : nullptr);
+        }
+        if (kc + 1 >= nch) break;
+        wait_vm(0);
+        lds_barrier();
+        if (kc + 2 < nch) dma_lin<0>(c, xsrc + (int64_t)(kc + 2) * XIMG_BYTES, Qb + ((kc + 2) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
+        request_pass(kc + 2, ea0, ea1);
+        {
+          const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + ((kc + 1) & 1) * XIMG_BYTES);
+          wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc + 1), adam_on ? &eb0 : nullptr, adam_on ? &eb1 : nullptr);
+        }
       }
       prof(c, PH_ENCB_L0_WGRAD);
     }
@@ -1847,7 +1933,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   dgrad_acc(c, acc, c.P, W2, N2, N1, N2 / 32, 0);
   lds_barrier();                                 // W2 fully read before its update
   float* const hpatch = c.stage + SPATCH_OFF / 4;
-  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N2, N1, 0, N1, WgT{J->reg_w[1], -1, nullptr, 0, nullptr, hpatch});
+  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, WgGeom{N2, N1, 0, N1, WgT{J->reg_w[1], -1, nullptr, 0, nullptr, hpatch}});
   relaunder(c);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {                  // P <- delta h1 = acc * relu'(h1)
@@ -1906,7 +1992,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
       }
     }
     lds_barrier();                               // W1 chunk fully read before its update
-    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N1, SD, k0, rup(valid, 16), WgT{J->reg_w[0], -1, nullptr, 0, nullptr, hpatch});
+    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, WgGeom{N1, SD, k0, rup(valid, 16), WgT{J->reg_w[0], -1, nullptr, 0, nullptr, hpatch}});
   }
 }
 
@@ -2183,7 +2269,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   if (c.tid < C) for (int r = 0; r < ROWS; ++r) gb += (float)c.P[r * LDP + c.tid];
   lds_barrier();                                   // Wo fully read before its update
   float* const hpatch = c.stage + SPATCH_OFF / 4;
-  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, C, Kl, 0, rup(Kl, 16), WgT{J->cls_w[Lc], -1, nullptr, 0, nullptr, hpatch});
+  wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, WgGeom{C, Kl, 0, rup(Kl, 16), WgT{J->cls_w[Lc], -1, nullptr, 0, nullptr, hpatch}});
   if (c.tid < C) apply_grad(c, J->cls_b[Lc] + c.tid, gb);
   // ---- backward: hidden blocks ----
   for (int li = Lc - 1; li >= 0; --li) {
@@ -2255,7 +2341,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
     zero_acc(acc);
     dgrad_acc(c, acc, c.P, Wl, N, K, rup(N, 32) / 32, 0);
     lds_barrier();
-    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, N, K, 0, rup(K, 16), WgT{J->cls_w[li], -1, nullptr, 0, nullptr, hpatch});
+    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, WgGeom{N, K, 0, rup(K, 16), WgT{J->cls_w[li], -1, nullptr, 0, nullptr, hpatch}});
     if (c.tid < N) apply_grad(c, J->cls_b[li] + c.tid, gbi);
   }
   // ---- d CE / d z ----

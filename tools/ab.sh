@@ -1,15 +1,13 @@
 #!/bin/bash
-# A/B of library variants on one box: tools/ab.sh <tag> <libA> <libB> ...  (ablate SE-gPoE + SM per variant, interleaved; with and without --xcd)
+# A/B of library variants on one box: tools/ab.sh <tag> <libA> <libB> ...  (ablate SE-gPoE + SM per variant, interleaved, 2 reps)
 TAG=$1; shift
 OUT=gpurun_out/ab_$TAG.txt
 : > $OUT
 for rep in 1 2; do
   for lib in "$@"; do
-    for x in "" "--xcd"; do
-      for proc in SE-gPoE SM-T1w_sMRI; do
-        echo -n "$lib $x rep$rep " >> $OUT
-        NMHIP_LIB_NAME=$lib python tools/ablate.py --procedure $proc $x 2>/dev/null | tail -1 >> $OUT
-      done
+    for proc in SE-gPoE SM-T1w_sMRI; do
+      echo -n "$lib rep$rep " >> $OUT
+      NMHIP_LIB_NAME=$lib python tools/ablate.py --procedure $proc 2>/dev/null | tail -1 >> $OUT
     done
   done
 done
