@@ -52,7 +52,8 @@ enum {
   NM_F_PROFILE  = 16,  /* workgroup (0,0) accumulates per-phase shader-clock cycles   */
   NM_F_ZGIVEN   = 32,  /* job.eps holds the latent z itself: decode(z, c, m), cVAE.py:1135 */
   NM_F_TRACE    = 64,  /* workgroup (0,0): per-wave interval timers between in-kernel stamps */
-  NM_F_BNSTATS  = 256  /* nm_head_classifier: update BatchNorm running statistics (once per train-mode forward) */
+  NM_F_BNSTATS  = 256, /* nm_head_classifier: update BatchNorm running statistics (once per train-mode forward) */
+  NM_F_SPLIT    = 512  /* set by nm_launch_split: one workgroup per (job, modality) */
 };
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the
@@ -197,6 +198,14 @@ int nm_validate_job(const nm_job_t* job_host);
  * Inference: one tile per 256 rows. */
 int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles,
               int flags, void* stream);
+
+/* Small sweeps (fewer models than CUs / M): every model runs as `parts` = M workgroups, one per modality (its encoder
+ * and decoder), placed on one XCD.  The parts meet twice per step through agent-scope hand-offs in the job's workspace
+ * (after the encoders: the experts' mu / logvar; after the decoders: d z and the per-modality log-likelihoods); every
+ * other byte a part touches is its own.  flags must include NM_F_BACKWARD; every job needs M == parts; results are
+ * bit-identical to nm_launch.  Status -16: ceil(n_jobs / 8) * 8 * parts exceeds the CU count (the parts wait for each
+ * other inside the launch, so all of them must be resident). */
+int nm_launch_split(const nm_job_t* jobs_dev, int n_jobs, int parts, int step0, int n_steps, int flags, void* stream);
 
 /* Convenience wrappers over nm_launch (same status convention). */
 int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream);

@@ -87,6 +87,8 @@ struct Ctx {
   __bf16* Q;
   float* stage;      // [STAGE_FLOATS] S
   float* vec;        // [2][256] fp32 vector slots (biases / logvar_out that travel with a weight image)
+  int part, nparts;  // NM_F_SPLIT: this workgroup runs modality `part` of the job (of nparts); -1: the whole job
+  int lstep;         // step index inside this launch (hand-off targets)
   float* red;        // [64] reduction scratch
   float* colacc;     // [128] per-column accumulators
   float* rowacc;     // [256] per-row accumulators
@@ -106,25 +108,33 @@ __host__ __device__ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int wpad(int n) { return rup(n + 1, 32); }   // width incl. the ones column
 
 // ---- workspace layout (shared by host and device) ------------------------------------------
+// One workspace per concurrently running tile of a job.  When the modalities of a model run as separate workgroups
+// (NM_F_SPLIT) they share it: the expert statistics are double-buffered by step parity (a part may already be one
+// step ahead), and every part has its own joint statistics / d z / decoder activations / z|c slot.
 struct WsLayout {
-  int64_t mu_m, lv_m, mu_j, lv_j, es, dz, enc_act, dec_act, zc, total;
+  int64_t sync, mu_m, lv_m, mu_j, lv_j, es, dz, enc_act, dec_act, zc, total;
+  int64_t lat, act;        // bytes of one [256][Zs] fp32 array / of one activation image
   int Zs;
 };
+constexpr int WS_SYNC_BYTES = 256;       // hand-off counters of the split mode: A at +0, B at +64, error flag at +128
 __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
   WsLayout w;
   w.Zs = rup(Z, 16);
   int64_t o = 0;
-  int64_t lat = (int64_t)ROWS * w.Zs * 4;
-  w.mu_m = o; o += lat * M;
-  w.lv_m = o; o += lat * M;
-  w.mu_j = o; o += lat;
-  w.lv_j = o; o += lat;
-  w.es = o; o += lat;
-  w.dz = o; o += lat;
-  int64_t act = (int64_t)ROWS * LDP * 2;       // activation images (LDS layout, reloaded by LDS-DMA)
+  w.sync = o; o += WS_SYNC_BYTES;
+  const int64_t lat = (int64_t)ROWS * w.Zs * 4;
+  w.lat = lat;
+  w.mu_m = o; o += lat * M * 2;                // [step parity][expert]
+  w.lv_m = o; o += lat * M * 2;
+  w.mu_j = o; o += lat * M;                    // [part]
+  w.lv_j = o; o += lat * M;
+  w.es = o; o += lat * M;
+  w.dz = o; o += lat * M;
+  const int64_t act = (int64_t)ROWS * LDP * 2; // activation images (LDS layout, reloaded by LDS-DMA)
+  w.act = act;
   w.enc_act = o; o += act * M * L;
-  w.dec_act = o; o += act * L;
-  w.zc = o; o += act;
+  w.dec_act = o; o += act * M * L;             // [part][layer]
+  w.zc = o; o += act * M;                      // [part]
   w.total = (o + 255) / 256 * 256;
   return w;
 }
@@ -404,6 +414,30 @@ __device__ __forceinline__ void wait_vm(int n) {
 // wavefronts; the explicit drain makes the hand-off independent of that.)
 __device__ __forceinline__ void handoff_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// Hand-off between the workgroups that share a model (NM_F_SPLIT): every part arrives at a monotonic counter once
+// its stores are globally visible, and leaves once all parts of the job have arrived.  Form: every wave drains its
+// own stores, the workgroup meets, one lane releases at agent scope (write-back of this XCD's L2), adds its arrival,
+// polls relaxed, acquires at agent scope (this CU's L1 is invalidated) -- MI355X_MICROARCH.md, "Valid forms".
+// The spin is bounded: on a time-out the error word is set and the step goes on (the host checks it).
+__device__ __forceinline__ void split_handoff(const Ctx& c, GAS unsigned* cnt, GAS unsigned* err, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (c.tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add((unsigned*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load((unsigned*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1 << 22)) { __hip_atomic_store((unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 
@@ -1112,15 +1146,21 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const WsLayout wl = ws_layout(M, L, Z);
   const int Zs = wl.Zs;
   const float rZ = 1.0f / (float)Z;
-  gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m);
-  gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m);
-  gf32 ws_mu_j = (gf32)(c.ws + wl.mu_j);
-  gf32 ws_lv_j = (gf32)(c.ws + wl.lv_j);
-  gf32 ws_es = (gf32)(c.ws + wl.es);
-  gf32 ws_dz = (gf32)(c.ws + wl.dz);
+  const bool split = c.part >= 0;               // this workgroup runs one modality of the model (NM_F_SPLIT)
+  const int part = split ? c.part : 0;
+  gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m + (int64_t)(step & 1) * M * wl.lat);
+  gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m + (int64_t)(step & 1) * M * wl.lat);
+  gf32 ws_mu_j = (gf32)(c.ws + wl.mu_j + part * wl.lat);
+  gf32 ws_lv_j = (gf32)(c.ws + wl.lv_j + part * wl.lat);
+  gf32 ws_es = (gf32)(c.ws + wl.es + part * wl.lat);
+  gf32 ws_dz = (gf32)(c.ws + wl.dz + part * wl.lat);
   GAS char* ws_enc = c.ws + wl.enc_act;         // activation images [256][LDP], ACT_BYTES each
-  GAS char* ws_dec = c.ws + wl.dec_act;
-  GAS char* ws_zc = c.ws + wl.zc;
+  GAS char* ws_dec = c.ws + wl.dec_act + (int64_t)part * L * wl.act;
+  GAS char* ws_zc = c.ws + wl.zc + part * wl.act;
+  GAS unsigned* sync_a = (GAS unsigned*)(c.ws + wl.sync);
+  GAS unsigned* sync_b = sync_a + 16;
+  GAS unsigned* sync_err = sync_a + 32;
+  const unsigned sync_target = (unsigned)(c.lstep + 1) * (unsigned)c.nparts;
   GAS char* wsh = (GAS char*)J->wsh;
   char* const Sb = reinterpret_cast<char*>(c.stage);
   char* const Qb = reinterpret_cast<char*>(c.Q);
@@ -1128,6 +1168,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 
   // ================= encoders =================
   for (int m = 0; m < Me; ++m) {
+    if (split && m != part) continue;
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     gbf16 save0 = bwd ? (gbf16)(ws_enc + (int64_t)(m * L + 0) * ACT_BYTES) : (gbf16)nullptr;
@@ -1150,9 +1191,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
 
   // ================= fusion + reparameterisation + KL =================
-  handoff_barrier();                             // the heads' mu / logvar stores are complete
+  // the heads' mu / logvar stores are complete (split: of every part, made visible across workgroups)
+  if (split) split_handoff(c, sync_a, sync_err, sync_target);
+  else handoff_barrier();
   // first decoder layer's image: requested now, lands during the latent arithmetic
-  issue_next(c, blob_to_half(c, wsh + J->mod[0].dec_s[0], 0));
+  issue_next(c, blob_to_half(c, wsh + J->mod[split ? part : 0].dec_s[0], 0));
   float al[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
   if (J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass)) softmax_alpha(J, al);
   auto load_lat = [&](Lat& Lt, int r, int z) {
@@ -1181,7 +1224,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     ws_dz[r * Zs + z] = 0.f;
     if (r < c.nrows) {
       kl_part += -0.5f * (1.0f + f.lv - f.mu * f.mu - expf(f.lv));
-      if (exportf) {
+      if (exportf && part == 0) {
         int64_t gr = (int64_t)(c.row0 + r) * Z + z;
         if (J->out_mu) asg(J->out_mu)[gr] = f.mu;
         if (J->out_logvar) asg(J->out_logvar)[gr] = f.lv;
@@ -1197,13 +1240,14 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // ================= decoders (forward, NLL, and the whole decoder backward) =================
   float ll_sum = 0.f;
   for (int m = 0; m < M; ++m) {
+    if (split && m != part) continue;
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int D = md.D;
     const int Kd0 = Z + C;
-    if (m > 0) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
+    if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
     // z | c | 1: built by the first decoder; the others reuse it when all tables carry the same covariates
-    const bool reuse_zc = J->shared_cov && M > 1;
+    const bool reuse_zc = J->shared_cov && M > 1 && !split;
     if (m == 0 || !reuse_zc) {
       build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
       lds_barrier();
@@ -1472,15 +1516,32 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
 
   // ================= loss log =================
-  if (c.tid == 0 && J->loss_log) {
+  // d z (and, split: ll_m) of every decoder is complete
+  if (split) split_handoff(c, sync_b, sync_err, sync_target);
+  else handoff_barrier();
+  if (c.tid == 0 && J->loss_log && part == 0) {
     gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
+    if (split) {                                  // the other parts logged their ll_m before they arrived
+      ll_sum = 0.f;
+      for (int m = 0; m < M; ++m) ll_sum += row[NM_LOSS_LL_M + m];
+    }
     row[NM_LOSS_KL] = J->kl_weight * kl;
     row[NM_LOSS_LL] = ll_sum;
     row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
   }
   if (!bwd) return;
+  if (split && part >= Me) return;                // a decoder-only part has no encoder to differentiate
   prof(c, PH_ALPHA);
-  handoff_barrier();                              // d z of every decoder is complete
+  // d z = sum over the decoders, in decoder order (single workgroup: accumulated in place in that order)
+  auto load_dz = [&](int r, int z) {
+    float d = ws_dz[r * Zs + z];
+    if (split) {
+      gcf32 base = (gcf32)(c.ws + wl.dz);
+      d = base[r * Zs + z];
+      for (int q = 1; q < M; ++q) d += base[(int64_t)q * ROWS * Zs + r * Zs + z];
+    }
+    return d;
+  };
 
   // ================= fusion backward: alpha gradients (gPoE) =================
   const bool fused = !(Me == 1 && J->single_bypass);
@@ -1490,8 +1551,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // expert go side by side into Q (expert m in columns [m 2Zs, (m+1) 2Zs) = [d mu_m | d logvar_m]), from there into
   // the (dead) z|c slot of the workspace, and each encoder's backward below starts from a 16-byte copy of its
   // columns.  Falls back to one evaluation per encoder when the deltas do not fit in 128 columns.
-  const bool once = fused && Me >= 2 && Me * 2 * Zs <= PW;
-  if (once || (fused && J->combine == NM_COMBINE_GPOE)) {
+  const bool once = fused && Me >= 2 && Me * 2 * Zs <= PW && !split;
+  // (split: the alpha sums ride on the part's own evaluation of the fusion backward, below)
+  if (once || (fused && J->combine == NM_COMBINE_GPOE && !split)) {
     relaunder(c);
     float dal[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
     if (once) {                                    // zero pads of every expert's block: columns [Z, Zs) of both halves
@@ -1507,7 +1569,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       int r = idiv(e, Z, rZ), z = e - r * Z;
       Lat Lt;
       load_lat(Lt, r, z);
-      float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
+      float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
       if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
       float dmu_j = dz + klw * mj;
       float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
@@ -1532,7 +1594,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         for (int m = 0; m < NM_MAX_EXP; ++m) dot += al[m] * tot[m];
 #pragma unroll
         for (int m = 0; m < NM_MAX_EXP; ++m)
-          if (m < Me) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot), nullptr);   // softmax backward
+          if (m < Me && (!split || m == part)) apply_grad(c, J->mod[m].alpha, al[m] * (tot[m] - dot), nullptr);   // softmax backward
       }
     }
     lds_barrier();
@@ -1544,6 +1606,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // ================= encoders, backward =================
   float* const spatch = reinterpret_cast<float*>(Sb + SPATCH_OFF);
   for (int m = 0; m < Me; ++m) {
+    if (split && m != part) continue;
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
     const int Hh = J->H[L - 1];
@@ -1561,6 +1624,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         *reinterpret_cast<u32x4*>(c.P + row * LDP + seg * 8) = *(const GAS u32x4*)(ws_fz + row * PW + m * 2 * Zs + seg * 8);
       }
     } else {
+      float dal_s[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
       const int npad = whp - 2 * Z;
       const float rnp = npad > 0 ? 1.0f / (float)npad : 0.f;
       for (int e = c.tid; e < ROWS * npad; e += WG) {
@@ -1573,7 +1637,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         int r = idiv(e, Z, rZ), z = e - r * Z;
         Lat Lt;
         load_lat(Lt, r, z);
-        float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = ws_dz[r * Zs + z];
+        float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
         if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
         float dmu_j = dz + klw * mj;
         float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
@@ -1581,6 +1645,19 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         const bool rv = r < c.nrows;
         c.P[r * LDP + z] = (__bf16)(rv ? pick(G.dmu, m) : 0.f);
         c.P[r * LDP + Zs + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
+#pragma unroll
+        for (int q = 0; q < NM_MAX_EXP; ++q) dal_s[q] += rv ? G.dal[q] : 0.f;
+      }
+      if (split && fused && J->combine == NM_COMBINE_GPOE) {       // this part's alpha: softmax backward of the sums
+        float tot[NM_MAX_EXP];
+#pragma unroll
+        for (int q = 0; q < NM_MAX_EXP; ++q) tot[q] = block_sum(c, dal_s[q]);
+        if (c.tid == 0) {
+          float dot = 0.f;
+#pragma unroll
+          for (int q = 0; q < NM_MAX_EXP; ++q) dot += al[q] * tot[q];
+          apply_grad(c, md.alpha, pick(al, m) * (pick(tot, m) - dot), nullptr);
+        }
       }
     }
     wait_vm(0);
@@ -1694,11 +1771,22 @@ __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
 
 template <bool SCALAR_TR>
 __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict__ jobs, int step0, int steps_per_tile,
-                                                     int flags) {
+                                                     int flags, int n_jobs, int nparts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const nm_job_t* J = jobs + blockIdx.x;
+  int job_idx = blockIdx.x, part = -1;
+  if (flags & NM_F_SPLIT) {
+    // workgroups b and b + 8 share an XCD (observed placement; speed only): the parts of a job are consecutive
+    // workgroups of ONE XCD, so that their hand-offs and shared expert statistics stay inside one L2
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    job_idx = (idx / nparts) * 8 + xcd;
+    part = idx % nparts;
+    if (job_idx >= n_jobs) return;
+  }
+  const nm_job_t* J = jobs + job_idx;
   Ctx c;
   c.job = J;
+  c.part = part;
+  c.nparts = nparts;
   carve_lds(c, smem);
   relaunder(c);
   c.flags = flags;
@@ -1716,6 +1804,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   const int s_begin = step0 + blockIdx.y * steps_per_tile;
   for (int s = s_begin; s < s_begin + steps_per_tile; ++s) {
     int b = s % nb;
+    c.lstep = s - s_begin;
     c.row0 = b * ROWS;
     c.nrows = min(ROWS, J->n_rows - c.row0);
     c.inv_b = 1.0f / (float)c.nrows;
@@ -1810,6 +1899,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   carve_lds(c, smem);
   relaunder(c);
   c.flags = flags & ~(NM_F_PROFILE | NM_F_TRACE);
+  c.part = -1; c.nparts = 1; c.lstep = 0;
   c.t_last = 0;
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -2037,6 +2127,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   carve_lds(c, smem);
   relaunder(c);
   c.flags = flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS);
+  c.part = -1; c.nparts = 1; c.lstep = 0;
   c.t_last = 0;
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -2390,6 +2481,15 @@ __device__ __forceinline__ void sync_matrix(const float* prm, int64_t w_off, int
     *reinterpret_cast<__bf16*>(dst) = h;
   }
 }
+// zero the split-mode hand-off counters of every job (before each NM_F_SPLIT launch)
+__global__ void sync_reset_kernel(const nm_job_t* __restrict__ jobs, int n_jobs) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_jobs * (WS_SYNC_BYTES / 4)) {
+    const nm_job_t* J = jobs + j / (WS_SYNC_BYTES / 4);
+    ((unsigned*)((char*)J->workspace + ws_layout(J->M, J->L, J->Z).sync))[j % (WS_SYNC_BYTES / 4)] = 0u;
+  }
+}
+
 __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
   const nm_job_t* J = jobs + blockIdx.x;
   const float* prm = J->params;
@@ -2609,6 +2709,7 @@ const char* nm_status_string(int status) {
     case -6: return "latent + c_dim exceeds NM_MAX_WIDTH";
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
+    case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
@@ -2706,24 +2807,45 @@ int64_t nm_workspace_bytes(const nm_job_t* j) {
 }
 
 static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
-                       void* stream, bool scalar_tr) {
+                       void* stream, bool scalar_tr, int parts = 1) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1 || steps_per_tile < 1 || n_tiles < 1 || step0 < 0) return -8;
   // concurrent tiles of one job share its parameters, moments and gradient buffer: forward-only
   if (n_tiles > 1 && (flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return -8;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(n_jobs, n_tiles), block(WG);
+  flags &= ~NM_F_SPLIT;
+  if (parts > 1) {
+    // several workgroups per model: they wait for each other inside the launch, so every one of them must be
+    // resident at once -- one workgroup per CU (LDS), hence at most as many workgroups as the device has CUs
+    if (n_tiles != 1 || parts > NM_MAX_MOD || !(flags & NM_F_BACKWARD)) return -8;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return -8;
+    const int wgs = (n_jobs + 7) / 8 * 8 * parts;
+    if (wgs > cus) return -16;
+    grid = dim3(wgs, 1);
+    flags |= NM_F_SPLIT;
+    hipLaunchKernelGGL(sync_reset_kernel, dim3((n_jobs * (WS_SYNC_BYTES / 4) + 255) / 256), dim3(256), 0, st, jobs_dev, n_jobs);
+  }
   hipError_t e;
   if (scalar_tr) {
     e = hipFuncSetAttribute((const void*)nm_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nm_step_kernel<true>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags);
+    hipLaunchKernelGGL(nm_step_kernel<true>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags, n_jobs, parts);
   } else {
     e = hipFuncSetAttribute((const void*)nm_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nm_step_kernel<false>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags);
+    hipLaunchKernelGGL(nm_step_kernel<false>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags, n_jobs, parts);
   }
   return (int)hipGetLastError();
+}
+
+/* Small sweeps: every model runs as `parts` workgroups, one per modality (decoder), which meet twice per step (after
+ * the encoders: expert statistics; after the decoders: d z).  All jobs of the launch must have M == parts decoders.
+ * Results equal the one-workgroup launch bit for bit.  -16: more workgroups than CUs (they could not all be resident). */
+int nm_launch_split(const nm_job_t* jobs_dev, int n_jobs, int parts, int step0, int n_steps, int flags, void* stream) {
+  return launch_impl(jobs_dev, n_jobs, step0, n_steps, 1, flags, stream, false, parts);
 }
 
 int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,

@@ -401,22 +401,46 @@ class JobSet:
         _lib.check(fn(ptr, len(self.jobs), int(step0), int(steps_per_tile), int(n_tiles), int(flags),
                       _stream_ptr(self.device)), "nm_launch")
 
-    def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False):
-        """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam)."""
+    def split_parts(self) -> int:
+        """Workgroups per model for a training launch: the M modalities of a model as separate workgroups when the
+        set is small enough for all of them to be resident at once (nm_launch_split), else 1.  NMHIP_SPLIT=0 / 1
+        forces one / insists on several."""
+        M = len(self.jobs[0].kmods)
+        mode = os.environ.get("NMHIP_SPLIT", "auto")
+        if mode == "0" or M < 2 or any(len(j.kmods) != M for j in self.jobs):
+            return 1
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        fits = (len(self.jobs) + 7) // 8 * 8 * M <= cus
+        return M if fits else 1
+
+    def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False, split: Optional[bool] = None):
+        """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam).  Small sets run every
+        model as M workgroups (split=None: automatically; results are bit-identical either way)."""
         step0 = self.jobs[0].step
         if any(j.step != step0 for j in self.jobs):
             raise ValueError("jobs of one set must be at the same step")
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | (_lib.NM_F_PROFILE if profile else 0)
-        self._launch(step0, n_steps, 1, flags, scalar_tr)
+        parts = self.split_parts() if split is None else (len(self.jobs[0].kmods) if split else 1)
+        if parts > 1 and not scalar_tr:
+            ptr = self._upload(1)
+            _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), parts, int(step0), int(n_steps), int(flags),
+                                                _stream_ptr(self.device)), "nm_launch_split")
+        else:
+            self._launch(step0, n_steps, 1, flags, scalar_tr)
         for j in self.jobs:
             j.step += n_steps
             j.t += n_steps
 
-    def grads(self, step: Optional[int] = None, export: bool = True, scalar_tr: bool = False):
+    def grads(self, step: Optional[int] = None, export: bool = True, scalar_tr: bool = False, split: bool = False):
         """forward + loss + backward for one step; gradients land in job.grads (no update)."""
         s = self.jobs[0].step if step is None else step
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | (_lib.NM_F_EXPORT if export else 0)
-        self._launch(s, 1, 1, flags, scalar_tr)
+        if split:
+            ptr = self._upload(1)
+            _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), len(self.jobs[0].kmods), int(s), 1, int(flags),
+                                                _stream_ptr(self.device)), "nm_launch_split")
+        else:
+            self._launch(s, 1, 1, flags, scalar_tr)
 
     def forward(self, tile0: int = 0, n_tiles: Optional[int] = None):
         """forward-only over row tiles (one workgroup per (job, 256-row tile)); fills the exports."""

@@ -32,5 +32,22 @@ def test_scanner_flags_the_known_bad_pattern():
     assert [b[0] for b in bad] == [".LBB0_3"]
 
 
-def test_kernel_isa_has_no_spill_ahead_of_exec_restore():
-    assert _mod().main() == 0
+def test_kernel_isa_has_no_spill_ahead_of_exec_restore_and_step_kernel_does_not_spill():
+    """main() compiles the kernel once and checks both the EXEC hazard and the resource ceilings of
+    nm_step_kernel (every instantiation): 0 VGPR spills, 0 bytes of scratch."""
+    m = _mod()
+    assert m.main() == 0
+    assert m.STEP_KERNEL_LIMITS == {"vgpr_spill_count": 0, "private_segment_fixed_size": 0}
+
+
+def test_resource_parser():
+    txt = """
+    .name:           _ZN12_GLOBAL__N_114nm_step_kernelILb0EEEvPK6nm_jobiii
+    .private_segment_fixed_size: 268
+    .sgpr_spill_count: 201
+    .vgpr_count:     256
+    .vgpr_spill_count: 88
+"""
+    r = _mod().resources(txt)
+    assert list(r.values())[0] == {"private_segment_fixed_size": 268, "sgpr_spill_count": 201, "vgpr_count": 256,
+                                   "vgpr_spill_count": 88}

@@ -83,10 +83,18 @@ def test_single_class_surface():
     model.load_state_dict(g.weights("w0"))
     model.to(DEV)
     x, c = g.t("x0").to(DEV), g.t("c").long().to(DEV)
+    model._eps_override = g.t("eps").reshape(-1, g.Z)                   # the golden's injected draw
     fwd = model.forward(x, c)
     loss = model.loss_function(x, fwd)
+    model._eps_override = None
     assert set(fwd) == {"x_recon", "mu", "logvar"} and set(loss) == {"total", "kl", "ll"}
     assert rel_err(fwd["mu"].cpu(), g.t("mu")) < 2e-2                   # mu does not depend on the draw
+    # cVAE.loss_function values against the reference's own numbers (golden loss0 = total, kl, ll; same injected draw)
+    ref = [float(v) for v in g.t("loss0").reshape(-1)[:3]]
+    got = [float(loss["total"]), float(loss["kl"]), float(loss["ll"])]
+    assert abs(got[2] - ref[2]) <= 1e-4 * abs(ref[2]), (got, ref)         # reconstruction term: north-star bound
+    assert abs(got[0] - ref[0]) <= 1e-4 * abs(ref[0]), (got, ref)
+    assert abs(got[1] - ref[1]) <= 5e-3 * abs(ref[1]) + 1e-6, (got, ref)  # KL carries the encoder's bf16 operand rounding
     model.optimizer1.zero_grad(); loss["total"].backward(); model.optimizer1.step()
     # pred_recon of class cVAE decodes mu (cVAE.py:547-553): deterministic -> compare with the golden (after 1 step)
     model.load_state_dict(g.weights("w1"))
@@ -94,6 +102,53 @@ def test_single_class_surface():
     assert rel_err(torch.from_numpy(pr), torch.from_numpy(g.z["pred_recon"])) < 2e-2
     lat, latvar = model.pred_latent(pd.DataFrame(g.t("x0").numpy()), g.t("c").long().numpy(), DEV)
     assert rel_err(torch.from_numpy(lat), torch.from_numpy(g.z["pred_latent"])) < 2e-2
+
+
+def test_facade_forward_only_calls_take_more_than_one_tile():
+    """pred_recon / pred_latent / encode / decode on 300 subjects (two 256-row tiles, ragged second tile): the
+    reference calls them on whole test folds (multimodal_kfold_test_cvae_supervised.py:112,
+    multimodal_kfold_cvae_nmmlp.py:487).  Checked against the oracle; a train step on 300 rows is refused."""
+    g = Golden("single_small")
+    N = 300
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, g.dims[0], generator=gen)
+    c = torch.zeros(N, g.c_dim)
+    c[torch.arange(N), torch.randint(0, g.c_dim, (N,), generator=gen)] = 1.0
+    P = g.weights("w0")
+    model = nm.cVAE(g.dims[0], g.hidden, g.Z, g.c_dim, non_linear=True)
+    model.load_state_dict(P)
+    model.to(DEV)
+    rs = R.Spec(g.dims, g.hidden, g.Z, g.c_dim, kind="single")
+    mu_r, lv_r = R.encoder_fwd(P, rs, 0, x, c)
+    loc_r, _ = R.decoder_fwd(P, rs, 0, mu_r, c)
+    lat, latvar = model.pred_latent(pd.DataFrame(x.numpy()), c.long().numpy(), DEV)
+    assert lat.shape == (N, g.Z)
+    assert rel_err(torch.from_numpy(lat), mu_r) < 2e-2 and rel_err(torch.from_numpy(latvar), lv_r.exp()) < 2e-2
+    pr = model.pred_recon(pd.DataFrame(x.numpy()), c.long().numpy(), DEV)
+    assert pr.shape == (N, g.dims[0]) and rel_err(torch.from_numpy(pr), loc_r) < 2e-2
+    # rows of the second tile are real results, not padding
+    assert float(np.abs(pr[256:]).max()) > 0 and rel_err(torch.from_numpy(pr[256:]), loc_r[256:]) < 2e-2
+    with pytest.raises(ValueError):
+        model.forward(x.to(DEV), c.long().to(DEV))
+    # multimodal facade: encode / decode of one expert on 300 rows, pred_recon shapes
+    gm = Golden("dev_small")
+    mm = nm.cVAE_multimodal(gm.dims, gm.hidden, gm.Z, gm.c_dim, modalities=gm.M, non_linear=True)
+    Pm = gm.weights("w0")
+    mm.load_state_dict(Pm)
+    mm.to(DEV)
+    rsm = R.Spec(gm.dims, gm.hidden, gm.Z, gm.c_dim)
+    xs = [torch.randn(N, d, generator=gen) for d in gm.dims]
+    cm = torch.zeros(N, gm.c_dim)
+    cm[torch.arange(N), torch.randint(0, gm.c_dim, (N,), generator=gen)] = 1.0
+    mu, lv = mm.encode(xs[1].to(DEV), cm.to(DEV), 1)
+    mu_o, lv_o = R.encoder_fwd(Pm, rsm, 1, xs[1], cm)
+    assert mu.shape == (N, gm.Z) and rel_err(mu.cpu(), mu_o) < 2e-2 and rel_err(lv.cpu(), lv_o) < 2e-2
+    z = torch.randn(N, gm.Z, generator=gen)
+    loc = mm.decode(z.to(DEV), cm.to(DEV), 2).loc
+    loc_o, _ = R.decoder_fwd(Pm, rsm, 2, z, cm)
+    assert loc.shape == (N, gm.dims[2]) and rel_err(loc.cpu(), loc_o) < 2e-2
+    preds = mm.pred_recon([pd.DataFrame(v.numpy()) for v in xs], cm.long().numpy(), DEV, gm.combine)
+    assert [p.shape for p in preds] == [(N, d) for d in gm.dims] and all(np.isfinite(p).all() for p in preds)
 
 
 def test_sweep_end_to_end_small():

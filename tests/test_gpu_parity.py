@@ -265,3 +265,47 @@ def test_deviation_passes():
         assert rel_err(job.out_loc[m][:N].cpu(), torch.from_numpy(g.z[f"joint_pred{m}"])) < 2e-2
         ref = torch.from_numpy(g.z[f"joint_dev{m}"]).float()
         assert float((job.out_rowdev[m][:N].cpu() - ref).abs().max()) < 1e-2 * float(ref.max())
+
+
+@pytest.mark.parametrize("name", ["mm3_gpoe", "mm3_poe", "mm3_moe", "mm3_mopoe", "mm4_uca_gpoe", "mm2_z64"])
+def test_split_launch_equals_single_workgroup_bit_for_bit(name):
+    """nm_launch_split (one workgroup per modality, two hand-offs per step) against the one-workgroup launch: the
+    same gradients, and after 4 fused Adam steps the same parameters, moments and loss log, bit for bit."""
+    g = Golden(name)
+    out = []
+    for split in (False, True):
+        job = make_job(g, 0)
+        js = nm.JobSet([job])
+        js.grads(0, export=False, split=split)
+        torch.cuda.synchronize()
+        grads = job.grads.cpu().clone()
+        js.train(4, split=split)
+        torch.cuda.synchronize()
+        out.append((grads, job.params.cpu().clone(), job.adam_m.cpu().clone(), job.adam_v.cpu().clone(),
+                    job.loss_log.cpu().clone()))
+    for a, b, what in zip(out[0], out[1], ("grads", "params", "adam_m", "adam_v", "loss_log")):
+        assert torch.equal(a, b), (what, float((a - b).abs().max()))
+
+
+def test_split_launch_many_small_models_and_refusal():
+    """Twenty 3-modality models as 3 workgroups each (the reference's real sweep width, 5 folds x 4 procedures):
+    identical to the one-workgroup launch; a set that cannot be resident all at once is refused."""
+    g = Golden("mm3_gpoe")
+    res = []
+    for split in (False, True):
+        jobs = [make_job(g, 0) for _ in range(20)]
+        for i, j in enumerate(jobs):
+            j.seed = i
+            j.set_eps(None)                       # in-kernel draw, keyed by (seed, step, row, z)
+        js = nm.JobSet(jobs)
+        js.train(3, split=split)
+        torch.cuda.synchronize()
+        res.append(torch.stack([j.params for j in jobs]).cpu())
+    assert torch.equal(res[0], res[1])
+    assert not torch.equal(res[0][0], res[0][1])          # different draws -> different models
+    lib = _lib.load()
+    big = nm.JobSet([make_job(g, 0) for _ in range(96)])  # 96 x 3 = 288 workgroups > 256 CUs
+    ptr = big._upload(1)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.nm_launch_split(ptr, 96, 3, 0, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS, st) == -16
+    assert big.split_parts() == 1

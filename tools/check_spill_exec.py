@@ -43,18 +43,53 @@ def scan(asm_text: str):
     return bad
 
 
-def main():
+def resources(asm_text: str):
+    """{kernel name: {vgpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size}} from the
+    code-object metadata at the end of the ISA listing."""
+    out, cur = {}, None
+    for l in asm_text.split("\n"):
+        m = re.match(r"\s*\.name:\s+(\S+)", l)
+        if m and not l.strip().startswith(".name:           _ZN") and False:
+            pass
+        if m:
+            cur = m.group(1)
+        m2 = re.match(r"\s*\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", l)
+        if m2 and cur and "kernel" in cur:
+            out.setdefault(cur, {})[m2.group(1)] = int(m2.group(2))
+    return out
+
+
+# ceilings for the persistent step kernel: it must not spill vector registers or touch scratch in its loop
+STEP_KERNEL_LIMITS = {"vgpr_spill_count": 0, "private_segment_fixed_size": 0}
+
+
+def compile_isa() -> str:
     src = ROOT / "multi_modal_normative_modeling_amd" / "csrc" / "nmhip.hip"
     with tempfile.TemporaryDirectory() as d:
         out = Path(d) / "nmhip.s"
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                f"-I{ROOT / 'include'}", str(src), "-o", str(out)]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-        bad = scan(out.read_text())
+        return out.read_text()
+
+
+def main():
+    text = compile_isa()
+    bad = scan(text)
     print(f"blocks with scratch traffic ahead of the EXEC restore: {len(bad)}")
     for label, ln, sc in bad:
         print(" ", label, "line", ln, sc[:4])
-    return 1 if bad else 0
+    rc = 1 if bad else 0
+    for name, r in sorted(resources(text).items()):
+        short = name.split("N_1")[-1][:34]
+        print(f"  {short:36s} vgpr {r.get('vgpr_count', -1):3d}  vgpr spills {r.get('vgpr_spill_count', -1):3d}  "
+              f"sgpr spills {r.get('sgpr_spill_count', -1):3d}  scratch {r.get('private_segment_fixed_size', -1):4d} B")
+        if "nm_step_kernel" in name:
+            for k, lim in STEP_KERNEL_LIMITS.items():
+                if r.get(k, 0) > lim:
+                    print(f"  !! {name}: {k} = {r[k]} exceeds the ceiling {lim}")
+                    rc = 1
+    return rc
 
 
 if __name__ == "__main__":
