@@ -64,7 +64,8 @@ def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Ten
     pad = torch.full((max_rows, N_METRICS), float("nan"), dtype=torch.float32, device=device or local.device)
     pad[: local.shape[0]] = local.to(pad.device)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return pad[~torch.isnan(pad[:, 0])].cpu()
+        one = pad[~torch.isnan(pad[:, 0])].cpu()
+        return one[torch.argsort(one[:, 0])]
     bufs = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
     dist.all_gather(bufs, pad)
     allm = torch.cat(bufs).cpu()
@@ -73,13 +74,17 @@ def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Ten
 
 
 def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int, epochs: int, device, out_dir=None,
-              lr: float = 1e-4, steps_per_launch: int = 64, oversample_percentage: Optional[float] = None) -> torch.Tensor:
+              lr: float = 1e-4, steps_per_launch: int = 64, oversample_percentage: Optional[float] = None,
+              hidden: Sequence[int] = workload.HIDDEN, latent: int = workload.LATENT,
+              per_procedure_dirs: bool = False) -> torch.Tensor:
     """Train the given cells concurrently, run the ROI-wise deviation pass, return the metric rows.
     `oversample_percentage` switches the training rows to the train script's own recipe (utils.generate_kfold_ids:
     KFold over healthy + other, bootstrap resample with replacement, merged back in table order); None = the plain
     KFold split of the regression script."""
     if not cells:
         return torch.empty(0, N_METRICS)
+    # per_procedure_dirs: several procedures in one sweep that share modalities write the same (fold, modality) file
+    # names -- the CSVs then go to <out_dir>/<procedure>/ (the sweep entry point below does that)
     folds = prep.kfold_indices(len(cohort.iid), n_folds, 42)
     if oversample_percentage is not None:
         hc = cohort.dia == 1
@@ -90,7 +95,7 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         mods, combine = workload.procedure_modalities(c.procedure)
         xs, cov = prep.fold_train_tables(cohort, mods, folds[c.fold][0])
         tables = [Table(x, cov, device) for x in xs]
-        spec = ModelSpec([t.D for t in tables], list(workload.HIDDEN), workload.LATENT, workload.C_DIM)
+        spec = ModelSpec([t.D for t in tables], list(hidden), int(latent), workload.C_DIM)
         jobs.append(Job(spec, tables, combine=combine, lr=lr, seed=1000 * c.fold + c.job_id, init_seed=42 + c.job_id,
                         loss_cap=max(8, epochs * 8)))
     # cells of different shapes take different time per step: group by shape so a launch is balanced
@@ -125,7 +130,8 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
             dev, rowdev, iids = deviation_roiwise(j, m, cohort, name, device, want_matrix=out_dir is not None)
             per_subject.append(rowdev)
             if out_dir is not None:
-                io.write_roiwise_csv(out_dir, c.fold, name if c.replica == 0 else f"{name}_r{c.replica}", iids, dev)
+                io.write_roiwise_csv(Path(out_dir) / c.procedure if per_procedure_dirs else out_dir, c.fold,
+                                     name if c.replica == 0 else f"{name}_r{c.replica}", iids, dev)
         scores.append(torch.stack(per_subject).mean(dim=0))
     pm = metrics.posthoc_metrics(scores, [dx] * len(cells), device=device).cpu()
     rows = []
@@ -330,3 +336,108 @@ def test_fold(job: Job, cohort: prep.SyntheticCohort, train_rows: np.ndarray, te
             cols = list(roi_columns[m]) if roi_columns and m in roi_columns else [f"{m}_{k}" for k in range(xs[i].shape[1])]
             io.write_test_csvs(Path(out_dir) / m, m, meta, cols, xs[i], x_hat)
     return errors
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Entry point: the reference's train script as ONE sharded sweep,
+#     python -m torch.distributed.run --nproc-per-node N -m multi_modal_normative_modeling_amd.sweep -R HCPimage \
+#         -P SM-T1w_sMRI SM-T2w_sMRI SM-fMRI UCA-gPoE -E 50 -K 5
+# (flag names of multimodal_kfold_train_cvae_supervised.py:216-299; the bash drivers there loop over -P, here the
+# procedures of one invocation form the grid).  plan_cells -> assign(rank, world) -> run_cells -> gather_metrics:
+# every rank trains its cells inside the persistent kernel and writes their ROI-wise CSVs; the one collective is the
+# all_gather of the metric table, which rank 0 writes as sweep_metrics.csv.
+# ---------------------------------------------------------------------------------------------------------------
+def build_parser():
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m multi_modal_normative_modeling_amd.sweep", description=__doc__)
+    ap.add_argument("-R", "--dataset_resourse", dest="dataset_resourse", type=str, default="HCPimage",
+                    help="dataset name (labels the output directory; the cohort is synthetic: the reference's data/ is not distributed)")
+    ap.add_argument("-H", "--hz_para_list", dest="hz_para_list", nargs="+", type=int, default=[110, 110, 10],
+                    help="hidden widths followed by the latent width")
+    ap.add_argument("-C", "--combine", dest="combine", type=str, default=None, help="overrides the combine part of every -P")
+    ap.add_argument("-P", "--procedure", dest="procedure", nargs="+", type=str, default=["UCA-gPoE"],
+                    help="one or more of SM-<modality> | SE-<combine> | UCA-<combine>")
+    ap.add_argument("-E", "--epochs", dest="epochs", type=int, default=200)
+    ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=10)
+    ap.add_argument("-O", "--oversample_percentage", dest="oversample_percentage", type=float, default=1.0)
+    ap.add_argument("-Model", "--model", dest="model", type=str, default="cVAE_multimodal")
+    ap.add_argument("-SingleModality", "--single_modality", dest="single_modality", type=str, default=None)
+    ap.add_argument("-Baselearningrate", "--base_learning_rate", dest="base_learning_rate", type=float, default=1e-4)
+    ap.add_argument("-Maxlearningrate", "--max_learning_rate", dest="max_learning_rate", type=float, default=0.005,
+                    help="accepted for compatibility: the train script's cyclic schedule never reaches the optimizer (it assigns an "
+                         "attribute Adam does not read, :180-186), so training runs at the base rate there and here")
+    ap.add_argument("-TrainingClass", "--training_class", dest="training_class", type=str, default="nm")
+    ap.add_argument("--subjects", type=int, default=1280, help="synthetic cohort size")
+    ap.add_argument("--replicas", type=int, default=1, help="independent seeds per (fold, procedure) cell")
+    ap.add_argument("--out-dir", type=str, default=None, help="deviation_fold_*_roiwise.csv + sweep_metrics.csv go here")
+    ap.add_argument("--no-csv", action="store_true", help="skip the ROI-wise CSVs (metrics only)")
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend when WORLD_SIZE > 1 (nccl = RCCL)")
+    return ap
+
+
+def main(argv=None, _run_cells=None) -> torch.Tensor:
+    """The sharded sweep; returns the gathered metric table on rank 0 (an empty tensor elsewhere).  `_run_cells`
+    replaces run_cells in the CPU rehearsal tests (the real one needs a GPU)."""
+    import os
+    args = build_parser().parse_args(argv)
+    if args.model != "cVAE_multimodal":
+        raise ValueError("Model not found")                                   # multimodal_kfold_train_cvae_supervised.py:170-171
+    procedures = list(args.procedure)
+    if args.single_modality:
+        procedures = [f"SM-{args.single_modality}"]
+    if args.combine:
+        procedures = [p if p.startswith("SM-") else f"{p.split('-')[0]}-{args.combine}" for p in procedures]
+    for p in procedures:
+        workload.procedure_modalities(p)                                      # raises on an unknown procedure
+    hidden, latent = list(args.hz_para_list[:-1]), int(args.hz_para_list[-1])
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and _run_cells is None
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    started = False
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and use_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        started = True
+    cohort = prep.synthetic_cohort(n=args.subjects, d=379)
+    cells = plan_cells(procedures, args.n_splits, args.replicas)
+    mine = assign(cells, rank, world)
+    out_dir = None
+    if args.out_dir is not None:
+        out_dir = Path(args.out_dir) / args.dataset_resourse
+        out_dir.mkdir(parents=True, exist_ok=True)
+    runner = _run_cells or run_cells
+    oversample = None if args.oversample_percentage == 1.0 and args.training_class == "nm" else args.oversample_percentage
+    # run_cells writes a cell's CSVs into <out>/<procedure>/ when procedures share modalities (per_procedure_dirs)
+    kw = {} if _run_cells is not None else {"per_procedure_dirs": True}
+    local = runner(cohort, mine, args.n_splits, args.epochs, device, out_dir=None if args.no_csv else out_dir,
+                   lr=args.base_learning_rate, oversample_percentage=oversample, hidden=hidden, latent=latent, **kw)
+    max_rows = (len(cells) + world - 1) // world
+    table = gather_metrics(local.to(device) if (world > 1 and dist.get_backend() == "nccl") else local, max_rows)
+    if rank == 0:
+        if table.shape[0] != len(cells):
+            raise RuntimeError(f"metric gather returned {table.shape[0]} rows for {len(cells)} cells")
+        if out_dir is not None:
+            import pandas as pd
+            df = pd.DataFrame(table.numpy(), columns=list(METRIC_COLUMNS))
+            df.insert(1, "procedure", [cells[int(j)].procedure for j in table[:, 0].tolist()])
+            df.to_csv(out_dir / "sweep_metrics.csv", index=False)
+        col = {n: i for i, n in enumerate(METRIC_COLUMNS)}
+        for p_id, proc in enumerate(procedures):
+            rows = table[table[:, col["proc_id"]] == p_id]
+            print(f"[sweep] {proc:28s} cells {rows.shape[0]:3d}  AUC {float(rows[:, col['roc_auc']].mean()):.4f} "
+                  f"+- {float(rows[:, col['roc_auc']].std(unbiased=False)):.4f}  final loss {float(rows[:, col['final_total_loss']].mean()):.2f}",
+                  flush=True)
+    if started:
+        dist.destroy_process_group()
+    return table if rank == 0 else torch.empty(0, N_METRICS)
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,24 @@ def test_facade_forward_only_calls_take_more_than_one_tile():
     assert [p.shape for p in preds] == [(N, d) for d in gm.dims] and all(np.isfinite(p).all() for p in preds)
 
 
+def test_sweep_cli_entry_one_gpu():
+    """python -m multi_modal_normative_modeling_amd.sweep with the reference's flag names, one rank: 2 procedures x 5
+    folds train inside the persistent kernel (the three-modality cells as three workgroups each), the ROI-wise CSVs of
+    every cell and sweep_metrics.csv land under <out>/<dataset>/."""
+    with tempfile.TemporaryDirectory() as d:
+        table = sweep.main(["-R", "HCPimage", "-P", "SM-T1w_sMRI", "SE-gPoE", "-E", "3", "-K", "5", "--subjects", "320",
+                            "--out-dir", d])
+        assert table.shape == (10, sweep.N_METRICS) and torch.isfinite(table).all()
+        out = __import__("pathlib").Path(d) / "HCPimage"
+        m = pd.read_csv(out / "sweep_metrics.csv")
+        assert list(m["job_id"]) == list(range(10)) and set(m["procedure"]) == {"SM-T1w_sMRI", "SE-gPoE"}
+        for k in range(5):
+            for proc, names in (("SM-T1w_sMRI", ("T1w_sMRI",)), ("SE-gPoE", ("T1w_sMRI", "T2w_sMRI", "fMRI"))):
+                for name in names:
+                    df = pd.read_csv(out / proc / f"deviation_fold_{k}_{name}_roiwise.csv")
+                    assert list(df.columns) == ["IID"] + [f"ROI_{i}" for i in range(379)] and len(df) == 320
+
+
 def test_sweep_end_to_end_small():
     """Two cells, a few epochs on a 320-subject synthetic cohort: training lowers the loss, the
     deviation CSVs have the reference layout and bit-exact IID / ROI indexing."""

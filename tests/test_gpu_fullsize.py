@@ -268,3 +268,57 @@ def test_in_kernel_normal_draw_statistics():
     assert abs(float((e[:, :-1] * e[:, 1:]).mean())) < 0.01 and abs(float((e[:-1] * e[1:]).mean())) < 0.01
     assert torch.equal(e, draws(7))
     assert float((e - draws(8)).abs().mean()) > 0.5
+
+
+@pytest.mark.parametrize("D,N", [(1137, 1064), (379, 1064), (379, 256)])
+def test_deviation_pass_at_size_vs_oracle(D, N):
+    """The ROI-wise deviation pass of multimodal_kfold_train_cvae_supervised_regression.py:163-192 at full size
+    (early-fusion width 1137, the 1064-subject table with its ragged 40-row last tile, 5 workgroups per model):
+    unimodal encode -> sampled z -> decode, (x - x_hat)^2 per ROI and its per-subject mean, against the oracle on
+    the same seeded inputs.  Bounds: within 1.5 x the distance between the fp32 and the bf16-operand oracle of the
+    bf16-operand one (plus fp32 summation noise), and within 3 x that distance of the reference's fp32 numbers;
+    indexing (row order, ROI order, the ragged tail, padding rows untouched) exactly."""
+    g = torch.Generator().manual_seed(D + N)
+    spec = nm.ModelSpec([D], [110, 110], 10, 29, True)
+    P = nm.ParamLayout(spec).init_reference_rule(7)
+    x = torch.randn(N, D, generator=g) * 1.1
+    c = onehot(g, N)
+    eps = torch.randn(N, 10, generator=g)
+    table = nm.Table(x, c, DEV)
+    job = nm.Job(spec, [table], combine="poe", state=P, n_tiles_ws=table.n_tiles)
+    nt = table.n_tiles
+    e = torch.zeros(nt * 256, 10)
+    e[:N] = eps
+    job.set_eps(e.view(nt, 256, 10))
+    job.enable_exports(loc=True, sqerr=True, rowdev=True, latent=True)
+    job.out_sqerr[0].fill_(-7.0)                      # sentinel: rows past N must stay untouched
+    nm.JobSet([job]).forward()
+    torch.cuda.synchronize()
+    rs = R.Spec([D], [110, 110], 10, 29, True)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        R.set_operand_rounding(mode)
+        try:
+            fwd = R.forward_multimodal(P, rs, [x], [c.long()], "poe", eps)
+            res[mode] = fwd["locs"][0].detach()
+        finally:
+            R.set_operand_rounding("fp32")
+    loc = job.out_loc[0][:N].cpu()
+    sq = job.out_sqerr[0][:N].cpu()
+    rd = job.out_rowdev[0][:N].cpu()
+    sq32, sq16 = (x - res["fp32"]) ** 2, (x - res["bf16"]) ** 2
+    noise_loc = float((res["bf16"] - res["fp32"]).abs().max())
+    noise_sq = float((sq16 - sq32).abs().max())
+    assert float((loc - res["bf16"]).abs().max()) <= 1.5 * noise_loc + 1e-5
+    assert float((sq - sq16).abs().max()) <= 1.5 * noise_sq + 1e-5
+    assert float((sq - sq32).abs().max()) <= 3.0 * noise_sq + 1e-5
+    assert float((sq - sq32).abs().max()) <= 2e-2 * float(sq32.max())            # the round-1 bound still holds
+    # exact self-consistency of the exports (same kernel arithmetic): sqerr == (x - loc)^2, rowdev == its ROI mean
+    assert torch.equal(sq, (x - loc) ** 2)
+    assert float((rd - sq.double().mean(dim=1).float()).abs().max()) <= 2e-6 * float(rd.max())
+    noise_rd = float((sq16.mean(dim=1) - sq32.mean(dim=1)).abs().max())
+    assert float((rd - sq32.mean(dim=1)).abs().max()) <= 3.0 * noise_rd + 1e-6
+    # padding rows of the last (ragged) tile were not written; pad columns of written rows are zero
+    assert bool((job.out_sqerr[0].cpu()[N:] == -7.0).all())
+    if table.x_pitch > D:
+        assert bool((job.out_sqerr[0].storage_offset() == 0))

@@ -90,6 +90,48 @@ def test_metric_gather_gloo_world2():
     assert set(allm[:, 4].tolist()) == {10.0, 20.0}                     # rows really came from both ranks
 
 
+def _stub_run_cells(cohort, cells, n_folds, epochs, device, out_dir=None, lr=1e-4, oversample_percentage=None, hidden=None,
+                    latent=None):
+    """Stand-in for the GPU work of sweep.run_cells: one metric row per cell, recognisable values."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    rows = [[c.job_id, c.fold, c.proc_id, 100.0 + c.job_id, 10.0 * (rank + 1), 0.5 + 0.01 * c.fold] + [0.25] * (sweep.N_METRICS - 6)
+            for c in cells]
+    assert list(hidden) == [64, 32] and latent == 7 and epochs == 3 and abs(lr - 2e-4) < 1e-12
+    return torch.tensor(rows, dtype=torch.float32).reshape(-1, sweep.N_METRICS)
+
+
+def _cli_worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank)})
+    table = sweep.main(["-R", "HCPimage", "-P", "SM-T1w_sMRI", "SM-fMRI", "UCA-gPoE", "-E", "3", "-K", "5", "-H", "64", "32", "7",
+                        "-Baselearningrate", "2e-4", "--subjects", "64", "--out-dir", out_dir, "--backend", "gloo"],
+                       _run_cells=_stub_run_cells)
+    assert (table.shape[0] == 15) == (rank == 0)
+
+
+def test_sweep_cli_entry_gloo_world2():
+    """The sharded entry point (reference flag names) under two ranks: plan -> assign -> run (stubbed) -> all_gather ->
+    sweep_metrics.csv on rank 0 with every cell exactly once."""
+    import pandas as pd
+    with tempfile.TemporaryDirectory() as d:
+        port = 29600 + (os.getpid() % 300)
+        mp.spawn(_cli_worker, args=(2, port, d), nprocs=2, join=True)
+        df = pd.read_csv(os.path.join(d, "HCPimage", "sweep_metrics.csv"))
+    assert list(df["job_id"]) == list(range(15))
+    assert set(df["procedure"]) == {"SM-T1w_sMRI", "SM-fMRI", "UCA-gPoE"}
+    assert set(df["steps_per_s"]) == {10.0, 20.0}                     # rows came from both ranks
+    # descending-cost round-robin: the five UCA cells (the expensive ones) are split 3 / 2 over the ranks
+    uca = df[df["procedure"] == "UCA-gPoE"]
+    assert sorted(uca["steps_per_s"].value_counts().tolist()) == [2, 3]
+
+
+def test_sweep_cli_rejects_unknown_model_and_procedure():
+    with pytest.raises(ValueError):
+        sweep.main(["-Model", "nope", "--subjects", "32"], _run_cells=_stub_run_cells)
+    with pytest.raises(ValueError):
+        sweep.main(["-P", "XX-gPoE", "--subjects", "32"], _run_cells=_stub_run_cells)
+
+
 def test_evaluate_regression_matches_sklearn():
     """sweep.evaluate_regression vs the sklearn calls of ..._regression.py:30-35."""
     from sklearn.metrics import mean_squared_error, mean_absolute_error, r2_score
