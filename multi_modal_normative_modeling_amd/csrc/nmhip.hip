@@ -1782,6 +1782,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     part = idx % nparts;
     if (job_idx >= n_jobs) return;
   }
+  const int tile_idx = blockIdx.y;
   const nm_job_t* J = jobs + job_idx;
   Ctx c;
   c.job = J;
@@ -1791,7 +1792,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   relaunder(c);
   c.flags = flags;
   c.t_last = 0;
-  c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
+  c.ws = (GAS char*)J->workspace + (int64_t)tile_idx * J->workspace_stride;
   // zero LDS once: padded columns are multiplied by zero weights and must stay finite
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
@@ -1801,7 +1802,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   if (steps_per_tile >= 64)
     for (int i = 0; i < J->dephase; ++i) __builtin_amdgcn_s_sleep(127);
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
-  const int s_begin = step0 + blockIdx.y * steps_per_tile;
+  const int s_begin = step0 + tile_idx * steps_per_tile;
   for (int s = s_begin; s < s_begin + steps_per_tile; ++s) {
     int b = s % nb;
     c.lstep = s - s_begin;

@@ -116,23 +116,25 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         js.assert_finite()
     torch.cuda.synchronize(device)
     sps = total_steps / max(time.perf_counter() - t0, 1e-9)
-    # deviation pass per cell; the per-subject score (mean over modalities of the ROI-mean deviation) stays on
-    # the GPU and feeds the metrics kernel (group_analysis_1x1.py:105-157); the ROI-wise matrix goes to the
-    # host only when a CSV is asked for
+    # deviation pass: ONE forward-only launch for every (cell, modality) of this rank (unimodal views of the trained
+    # models on the all-subject tables, one workgroup per (view, 256-row tile)); the per-subject score (mean over
+    # modalities of the ROI-mean deviation) stays on the GPU and feeds the metrics kernel
+    # (group_analysis_1x1.py:105-157); the ROI-wise matrices go to the host only when CSVs are asked for
     scores, finals = [], []
     dx = torch.as_tensor(cohort.dia == 0)
-    for c, j in zip(cells, jobs):
-        mods, _ = workload.procedure_modalities(c.procedure)
+    views = [(i, m, name) for i, c in enumerate(cells) for m, name in enumerate(workload.procedure_modalities(c.procedure)[0])]
+    devs = deviation_roiwise_many([(jobs[i], m, name) for i, m, name in views], cohort, device, want_matrix=out_dir is not None)
+    per_cell: Dict[int, list] = {}
+    for (i, m, name), (dev, rowdev) in zip(views, devs):
+        per_cell.setdefault(i, []).append(rowdev)
+        if out_dir is not None:
+            c = cells[i]
+            io.write_roiwise_csv(Path(out_dir) / c.procedure if per_procedure_dirs else out_dir, c.fold,
+                                 name if c.replica == 0 else f"{name}_r{c.replica}", cohort.iid, dev)
+    for i, (c, j) in enumerate(zip(cells, jobs)):
         last = (j.step - 1) % j.loss_cap
         finals.append(float(j.loss_log[last, 0]))
-        per_subject = []
-        for m, name in enumerate(mods):
-            dev, rowdev, iids = deviation_roiwise(j, m, cohort, name, device, want_matrix=out_dir is not None)
-            per_subject.append(rowdev)
-            if out_dir is not None:
-                io.write_roiwise_csv(Path(out_dir) / c.procedure if per_procedure_dirs else out_dir, c.fold,
-                                     name if c.replica == 0 else f"{name}_r{c.replica}", iids, dev)
-        scores.append(torch.stack(per_subject).mean(dim=0))
+        scores.append(torch.stack(per_cell[i]).mean(dim=0))
     pm = metrics.posthoc_metrics(scores, [dx] * len(cells), device=device).cpu()
     rows = []
     for i, c in enumerate(cells):
@@ -140,6 +142,44 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         rows.append([c.job_id, c.fold, c.proc_id, finals[i], sps, float(pm[i, 0]), float(pm[i, 1]), float(pm[i, 2]),
                      float(pm[i, 3]), float(pm[i, 4]), float(sc[~dx].mean()), float(sc[dx].mean())])
     return torch.tensor(rows, dtype=torch.float32)
+
+
+def deviation_roiwise_many(views, cohort: prep.SyntheticCohort, device, want_matrix: bool = True,
+                           covariates: Optional[np.ndarray] = None):
+    """deviation_roiwise for a list of (trained job, modality index, modality name) in ONE launch: the all-subject
+    table of a modality (scaler re-fit on all subjects, ..._regression.py:177-186) is built once and shared by every
+    view of that modality; each view is the unimodal model encoder m / decoder m of its job.  Returns
+    [(ROI-wise matrix on the host or None, per-subject ROI-mean deviation on the device)] in the order of `views`."""
+    if not views:
+        return []
+    from .layout import ParamLayout
+    c = prep.one_hot_covariates(cohort.age, cohort.gender) if covariates is None else covariates
+    tables: Dict[str, Table] = {}
+    ones = []
+    for job, m, name in views:
+        if name not in tables:
+            src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
+            center, scale = prep.robust_scaler_fit(src.astype(np.float32))
+            tables[name] = Table(prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32), c, device)
+        table = tables[name]
+        spec1 = ModelSpec([job.spec.input_dims[m]], list(job.spec.hidden), job.spec.latent, job.spec.c_dim)
+        sd = job.state_dict()
+        st = {k: sd[k.replace("_list.0.", f"_list.{m}.")] for k in ParamLayout(spec1).names}
+        one = Job(spec1, [table], combine="poe", state=st, seed=job.seed + 7919 * (m + 1), n_tiles_ws=table.n_tiles)
+        one.enable_exports(loc=False, sqerr=want_matrix, rowdev=True, latent=False)
+        ones.append(one)
+    # one launch per distinct table height (all-subject tables of one cohort: a single launch)
+    by_tiles: Dict[int, List[int]] = {}
+    for i, o in enumerate(ones):
+        by_tiles.setdefault(o.tables[0].n_tiles, []).append(i)
+    for idxs in by_tiles.values():
+        JobSet([ones[i] for i in idxs]).forward()
+    torch.cuda.synchronize(device)
+    out = []
+    for one in ones:
+        N = one.tables[0].N
+        out.append((one.out_sqerr[0][:N].cpu().numpy() if want_matrix else None, one.out_rowdev[0][:N].clone()))
+    return out
 
 
 def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str, device, want_matrix: bool = True,
