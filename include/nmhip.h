@@ -266,6 +266,26 @@ int64_t nm_xb_elems(int rows_alloc, int Kx);
 int nm_pack_table(const float* x, const float* c, int n_rows, int rows_alloc, int D, int C, int Kx,
                   uint16_t* xb, float* x_f32_out, int x_pitch, uint16_t* cz_out, int Cz, void* stream);
 
+/* ---- input preparation on the device (multi_modal_normative_modeling_amd/csrc/nm_prep.hip) -----------
+ * The raw cohort stays resident in HBM as fp64 tables [n_all][src_D[s]] (srcs_dev: device array of n_src device
+ * pointers; several sources = early fusion, modality-major column concat, early_fusion_modalities.py:23-32);
+ * rows_dev: int32 row indices of a fold.  Results are bit-identical to sklearn / pandas on the host (prep.py). */
+#define NM_PREP_MAX_ROWS 8192
+/* RobustScaler().fit on the rows: center[d] = median, scale[d] = 75 % - 25 % quantile (numpy linear interpolation), a
+ * zero range scales by 1 (multimodal_kfold_train_cvae_supervised.py:101-102).  One workgroup per ROI column. */
+int nm_prep_scaler_fit(const double* const* srcs_dev, const int32_t* src_D_dev, int n_src, int D, const int32_t* rows_dev,
+                       int n_rows, double* center_dev, double* scale_dev, void* stream);
+/* c = [eye(age_bins)[qcut(rank_first(AGE))] | eye(gender_bins)[qcut(rank_first(PTGENDER))]] as fp32 [n_rows][age_bins +
+ * gender_bins] (:107-126).  *_edges_dev: the q + 1 bin edges numpy computes for the ranks 1..n_rows (they depend on
+ * n_rows only; prep.qcut_edges). */
+int nm_prep_onehot(const double* age_dev, const double* gender_dev, const int32_t* rows_dev, int n_rows, const double* age_edges_dev,
+                   int age_bins, const double* gender_edges_dev, int gender_bins, float* c_out_dev, void* stream);
+/* nm_pack_table fed from the raw cohort: x = (float)((raw - center) / scale) for the given rows (RobustScaler.transform +
+ * astype(float32)), c_dev [n_rows][C] fp32; outputs as nm_pack_table. */
+int nm_pack_table_raw(const double* const* srcs_dev, const int32_t* src_D_dev, int n_src, const int32_t* rows_dev, int n_rows,
+                      const double* center_dev, const double* scale_dev, const float* c_dev, int rows_alloc, int D, int C, int Kx,
+                      uint16_t* xb, float* x_f32_out, int x_pitch, uint16_t* cz_out, int Cz, void* stream);
+
 /* Debug / unit-test entry: C[M][N] = A[M][K] * B[N][K]^T through the kernel's own fragment
  * loaders.  mode 0: A row-major via LDS, B fp32 weights (forward form); mode 1: dgrad form
  * (B read transposed); mode 2: wgrad form, both operands read transposed from LDS with

@@ -127,6 +127,9 @@ def load():
     lib.nm_confusion_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
     lib.nm_pack_table.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]
+    lib.nm_prep_scaler_fit.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    lib.nm_prep_onehot.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp]
+    lib.nm_pack_table_raw.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     lib.nm_prof_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
     lib.nm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
@@ -144,6 +147,7 @@ EXPORTED_SYMBOLS = [
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
     "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split",
+    "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
 ]
 
 

@@ -2710,6 +2710,7 @@ const char* nm_status_string(int status) {
     case -6: return "latent + c_dim exceeds NM_MAX_WIDTH";
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
+    case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
     case -8: return "bad launch geometry";

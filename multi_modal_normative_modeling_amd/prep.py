@@ -40,15 +40,20 @@ def rank_first(col: np.ndarray) -> np.ndarray:
     return ranks
 
 
+def qcut_edges(n: int, q: int) -> np.ndarray:
+    """Bin edges of pd.qcut over the ranks 1..n: pandas computes them as np.percentile(ranks, linspace(0,1,q+1)*100);
+    the same call is used here so that an edge landing on an integer rank rounds the same way (bit-exact bins).
+    They depend on n only (the device path, prep_device.py, takes them as constants)."""
+    return np.percentile(np.arange(1, n + 1, dtype=np.float64), np.linspace(0, 1, q + 1) * 100)
+
+
 def qcut_rank_bins(col: np.ndarray, q: int) -> np.ndarray:
     """pd.qcut(col.rank(method='first'), q, labels=range(q)) (..._supervised.py:107-112):
     equal-count bins of the sort order; bin edges are the linear-interpolated quantiles of the
     ranks 1..n, intervals are right-closed and the first one includes its left edge."""
     r = rank_first(col)
     n = len(r)
-    # pandas computes the edges as np.percentile(ranks, linspace(0,1,q+1)*100): use the same call so
-    # that an edge landing on an integer rank rounds the same way (bit-exact bins)
-    edges = np.percentile(np.arange(1, n + 1, dtype=np.float64), np.linspace(0, 1, q + 1) * 100)
+    edges = qcut_edges(n, q)
     bins = np.searchsorted(edges, r, side="left") - 1
     bins[r <= edges[0]] = 0
     return np.clip(bins, 0, q - 1).astype(np.int64)

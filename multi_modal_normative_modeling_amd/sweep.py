@@ -91,10 +91,13 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         ids = prep.generate_kfold_ids(cohort.iid[hc], cohort.iid[~hc], oversample_percentage, n_folds)
         folds = [(prep.rows_of_ids(cohort.iid, tr), prep.rows_of_ids(cohort.iid, te)) for tr, te in ids]
     jobs: List[Job] = []
+    # the fold's tables are built on the device from the raw cohort (scaler fit, covariate bins, early-fusion concat,
+    # packing: prep_device.py), once per (fold, modality); the cells of a fold share them
+    from .prep_device import DeviceCohort
+    dc = DeviceCohort(cohort, device)
     for c in cells:
         mods, combine = workload.procedure_modalities(c.procedure)
-        xs, cov = prep.fold_train_tables(cohort, mods, folds[c.fold][0])
-        tables = [Table(x, cov, device) for x in xs]
+        tables = dc.fold_tables_cached(c.fold, mods, folds[c.fold][0])
         spec = ModelSpec([t.D for t in tables], list(hidden), int(latent), workload.C_DIM)
         jobs.append(Job(spec, tables, combine=combine, lr=lr, seed=1000 * c.fold + c.job_id, init_seed=42 + c.job_id,
                         loss_cap=max(8, epochs * 8)))
