@@ -41,7 +41,10 @@ extern "C" {
 #define NM_MAX_LATENT 64
 
 /* expert fusion, cVAE.py:1144-1164 */
-enum { NM_COMBINE_POE = 0, NM_COMBINE_GPOE = 1, NM_COMBINE_MOE = 2, NM_COMBINE_MOPOE = 3 };
+enum { NM_COMBINE_POE = 0, NM_COMBINE_GPOE = 1, NM_COMBINE_MOE = 2, NM_COMBINE_MOPOE = 3,
+       /* mvtCAE's 'poe' (cVAE.py:1782-1783, 1481-1489): ProductOfExperts2 called with the VARIANCES in the place of its
+          logvar argument -- precisions exp(-var_m), and log(1 / sum of them) taken as the joint variance             */
+       NM_COMBINE_POE2V = 4 };
 
 /* mode flags of nm_launch */
 enum {
@@ -109,7 +112,21 @@ typedef struct nm_job {
   int32_t combine;        /* NM_COMBINE_*                                                */
   int32_t single_bypass;  /* 1: M == 1 skips fusion (cVAE.py:1146-1147)                  */
   int32_t n_rows;         /* valid rows in the tables                                    */
-  int32_t non_linear;     /* 1: LeakyReLU(0.01) between layers (cVAE.py:166-167)         */
+  int32_t non_linear;     /* 1: LeakyReLU(act_slope) between layers (cVAE.py:166-167)    */
+  float   act_slope;      /* negative slope: 0.01 = F.leaky_relu default (cVAE.py:167,203); 0 = ReLU (VariationalEncoder /
+                             VariationalDecoder of the DMVAE family, cVAE.py:1453-1479)                              */
+  int32_t out_kind;       /* decoder output / likelihood: 0 = Normal(loc, exp(logvar_out)^0.5) log-likelihood (cVAE.py:206, :14-15);
+                             1 = sigmoid output with ll = -0.5 sum (x - x_hat)^2 (DMVAE family, cVAE.py:1478, :1560) -- no logvar_out */
+  int32_t n_private;      /* DMVAE family (cVAE.py:1525-1529): the first n_private columns of every encoder's mu are that
+                             modality's PRIVATE latent -- passed to its own decoder as they are (no draw, no KL, logvar
+                             unused) --, the remaining Z - n_private columns are the shared latent that is fused,
+                             sampled and regularised; the decoder input is [shared z | private mu_m | c | 1].  0: all shared */
+  float   var_floor;      /* joint variance clamped from below before its log (mvtCAE: torch.clamp(variance_multimodal, min=1e-6),
+                             cVAE.py:1823); 0 = no clamp                                                             */
+  float   tc_weight;      /* weight of mvtCAE's total-correlation term in the total (cVAE.py:1862-1880): tc = - sum_z mean_m
+                             logsumexp_rows(mu_m[:, z]) (its joint-posterior half is identically zero there); 0 = none   */
+  int64_t w_off;          /* WeightedDMVAE.weights [M] in params (cVAE.py:1650): kl_i and ll_i are multiplied by weights[i]
+                             and the weights are learned; -1: none                                                    */
   int32_t dephase;        /* launches of >= 64 steps: the job's workgroup first sleeps dephase * 8128 cycles, so that
                              identical models do not run their HBM-heavy phases in lockstep (0 = off; the host spreads
                              the jobs of a launch over one step's worth of cycles, engine.py)                        */
@@ -119,6 +136,10 @@ typedef struct nm_job {
   int32_t eps_cap;        /* steps held by eps; step s reads block s % eps_cap           */
   float   lr, beta1, beta2, adam_eps;
   int64_t adam_off;       /* optimizer step count of data step s is adam_off + s + 1     */
+  const double* lr_table; /* optional per-step learning rate: optimizer step t (1-based) runs at lr_table[(t - 1) mod lr_cap]
+                             (the cyclic schedule that really reaches the optimizer, multimodal_kfold_cvae_nmmlp.py:376-381:
+                             param_group['lr'] = clr); NULL: the constant `lr`                                          */
+  int32_t lr_cap;         /* entries of lr_table                                          */
   float   kl_weight;      /* d total / d KL   (= M for cVAE_multimodal, cVAE.py:1189-1195) */
   float   ll_weight;      /* d total / d (-LL_m)                                          */
   float*  params;         /* flat fp32 parameters                                        */
@@ -171,6 +192,7 @@ typedef struct nm_job {
 #define NM_LOSS_KL    1
 #define NM_LOSS_LL    2
 #define NM_LOSS_LL_M  3
+#define NM_LOSS_TC    11   /* total-correlation term (mvtCAE), unweighted */
 #define NM_LOSS_REG   12   /* MSE of the regression head (nm_head_regression) */
 #define NM_LOSS_CE    13   /* cross entropy of the classifier head (nm_head_classifier) */
 #define NM_LOSS_CONTRAST 14 /* contrastive hinge of the classifier head */

@@ -19,7 +19,7 @@ NM_MAX_WIDTH = 127
 NM_MAX_LATENT = 64
 NM_LOSS_STRIDE = 16
 
-NM_COMBINE = {"poe": 0, "gpoe": 1, "moe": 2, "mopoe": 3}
+NM_COMBINE = {"poe": 0, "gpoe": 1, "moe": 2, "mopoe": 3, "poe2v": 4}
 
 NM_F_BACKWARD = 1
 NM_F_ADAM = 2
@@ -28,6 +28,7 @@ NM_F_EXPORT = 8
 NM_F_PROFILE = 16
 NM_F_ZGIVEN = 32
 NM_F_TRACE = 64
+NM_LOSS_TC = 11
 NM_LOSS_REG = 12
 NM_LOSS_CE = 13
 NM_LOSS_CONTRAST = 14
@@ -60,10 +61,12 @@ class NmJob(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("M_enc", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("Z", C.c_int32),
         ("H", C.c_int32 * NM_MAX_HID),
-        ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32), ("dephase", C.c_int32), ("shared_cov", C.c_int32),
+        ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32),
+        ("act_slope", C.c_float), ("out_kind", C.c_int32), ("n_private", C.c_int32),
+        ("var_floor", C.c_float), ("tc_weight", C.c_float), ("w_off", C.c_int64), ("dephase", C.c_int32), ("shared_cov", C.c_int32),
         ("loss_cap", C.c_int32), ("eps_cap", C.c_int32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("adam_off", C.c_int64),
+        ("adam_off", C.c_int64), ("lr_table", C.c_void_p), ("lr_cap", C.c_int32),
         ("kl_weight", C.c_float), ("ll_weight", C.c_float),
         ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("grads", C.c_void_p),
         ("eps", C.c_void_p), ("seed", C.c_uint64),

@@ -118,6 +118,20 @@ class _Base(nn.Module):
     def _build_tree(self):
         v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
         s, L = self.spec, len(self.spec.hidden)
+        if s.is_dm:                                 # encoder_list.{m}.fc1 ... / decoder_list.{m}.fc_out (cVAE.py:1453-1479)
+            def stack(prefix, layers):
+                mods = []
+                for m in range(s.M):
+                    mod = nn.Module()
+                    for l in layers:
+                        mod.add_module(l, _Holder(weight=v[f"{prefix}.{m}.{l}.weight"], bias=v[f"{prefix}.{m}.{l}.bias"]))
+                    mods.append(mod)
+                return nn.ModuleList(mods)
+            if "weights" in v:
+                self.register_parameter("weights", v["weights"])
+            self.encoder_list = stack("encoder_list", ("fc1", "fc2", "fc_mu", "fc_logvar"))
+            self.decoder_list = stack("decoder_list", ("fc1", "fc2", "fc_out"))
+            return
 
         def enc(m):
             p = s.enc_prefix(m)
@@ -328,6 +342,118 @@ class cVAE_multimodal(_Base):
 
     def reconstruction_deviation_multimodal(self, xes, x_preds):
         return [np.sum((xes[m] - x_preds[m]) ** 2, axis=1) / xes[m].shape[1] for m in range(self.modalities)]
+
+
+class DMVAE(_Base):
+    """cVAE.py:1491-1598 (baseline zoo) on the step kernel: covariate-free ReLU encoders, the first
+    min(c_dim, latent) latent columns private to their modality (handed to its decoder as they are), the rest fused by
+    ProductOfExperts2 and sampled; sigmoid decoders with ll = -0.5 sum (x - x_hat)^2; total = beta * kl - ll with the KL
+    counted once per modality.  `x_recons` are plain tensors here, as in the reference."""
+    _kind, _beta = "dmvae", 1.0
+
+    def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
+                 non_linear=False):
+        super().__init__()
+        if modalities != len(input_dim_list):
+            raise ValueError("modalities must equal len(input_dim_list)")
+        self.input_dim_list, self.hidden_dim = list(input_dim_list), list(hidden_dim)
+        self.latent_dim, self.c_dim, self.s_dim, self.beta = latent_dim, c_dim, c_dim, self._beta
+        self.modalities, self.learning_rate, self.non_linear = modalities, learning_rate, non_linear
+        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, True, self._kind), learning_rate,
+                    kl_weight=float(modalities) * self._beta)
+        self._single_bypass = False
+        self.optimizer1 = _Adam(self, learning_rate)
+
+    def _tables_c(self, n):
+        return torch.zeros(n, 0)                    # the networks take no covariates (encode(x, c, m) ignores c)
+
+    def forward_multimodal(self, xes, cs, combine):
+        self.zero_grad()
+        B = int(xes[0].shape[0])
+        eps = self._draw(B)
+        cz = [self._tables_c(B)] * self.modalities
+        j, B = self._run(xes, cz, "poe", _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | _lib.NM_F_EXPORT, eps=eps)
+        self._last = (list(xes), cz, "poe", eps)
+        zc = self.latent_dim - self.spec.n_private
+        return {"x_recons": [j.out_loc[m][:B].clone() for m in range(self.modalities)],
+                "mu_c": j.out_mu[:B, :zc].clone(), "logvar_c": j.out_logvar[:B, :zc].clone()}
+
+    def loss_function_multimodal(self, xes, fwd_rtn):
+        row = self._job.loss_log[0]
+        total = _LossFn.apply(self._anchor, self, "total", row[0])
+        # losses['kl'] is the sum over the modalities BEFORE beta (cVAE.py:1569-1574); the log holds beta * that
+        return {"total": total, "kl": (row[1] / self.beta).clone(), "ll": row[2].clone()}
+
+    def pred_recon(self, xes, cs, device, combine):
+        xs = [torch.tensor(np.asarray(x.values if hasattr(x, "values") else x), dtype=torch.float32) for x in xes]
+        self._dev()
+        j, B = self._run(xs, [self._tables_c(xs[0].shape[0])] * self.modalities, "poe", _lib.NM_F_EXPORT)
+        return [j.out_loc[m][:B].cpu().numpy() for m in range(self.modalities)]
+
+    def reparameterize(self, mu, logvar):
+        return self.reparameterise(mu, logvar)
+
+    def reconstruction_deviation_multimodal(self, xes, x_preds):
+        out = []
+        for m in range(self.modalities):
+            x = np.asarray(xes[m].values if hasattr(xes[m], "values") else xes[m])
+            out.append(np.sum((x - np.asarray(x_preds[m])) ** 2, axis=1) / x.shape[1])
+        return out
+
+
+class mmVAEPlus(DMVAE):
+    """cVAE.py:1895-2002: DMVAE with beta = 0.05."""
+    _kind, _beta = "mmvaeplus", 0.05
+
+
+class WeightedDMVAE(DMVAE):
+    """cVAE.py:1620-1747: DMVAE whose kl_i and ll_i are multiplied by learnable `weights[i]` (initialised
+    |N(0, 1)|).  The reference prints weight / KL / LL per modality from inside loss_function_multimodal (:1702);
+    that print is not reproduced."""
+    _kind = "weighted_dmvae"
+
+    def loss_function_multimodal(self, xes, fwd_rtn):
+        row = self._job.loss_log[0]
+        total = _LossFn.apply(self._anchor, self, "total", row[0])
+        return {"total": total, "kl": row[1].clone(), "ll": row[2].clone()}
+
+
+class mvtCAE(cVAE_multimodal):
+    """cVAE.py:1754-1893 (baseline zoo) on the step kernel: cVAE_multimodal's encoders / decoders /
+    alpha_m_list; no single-expert bypass; `combine='poe'` is ProductOfExperts2 fed with the VARIANCES where it expects
+    log variances (:1782-1783 -- kept as written: NM_COMBINE_POE2V); the joint variance is clamped at 1e-6; the loss is
+    sum_i [kl + 1e-5 ll_i + 1e-4 tc] (the log-likelihood with a plus sign, :1877), tc = the total-correlation term of
+    :1862-1869 whose joint half is identically zero.  `qz_xs` (the experts' means) is not returned (None): the loss is
+    formed inside the kernel."""
+
+    def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3, non_linear=False):
+        super().__init__(input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate, modalities, non_linear)
+        self.beta = 0.0001
+        self._setup(ModelSpec(list(input_dim_list), list(hidden_dim), latent_dim, c_dim, non_linear, "mvtcae"), learning_rate,
+                    kl_weight=float(modalities))
+        self._single_bypass = False
+        self._ll_weight = -1e-5
+        self.optimizer1 = _Adam(self, learning_rate)
+
+    @staticmethod
+    def _kernel_combine(combine):
+        if combine.lower() not in ("poe", "gpoe", "moe", "mopoe"):
+            raise ValueError("No such combination method")
+        return "poe2v" if combine.lower() == "poe" else combine
+
+    def forward_multimodal(self, xes, cs, combine):
+        out = super().forward_multimodal(xes, cs, self._kernel_combine(combine))
+        out["qz_xs"], out["qz_x"] = None, out["mu_multimodal"]
+        return out
+
+    def loss_function_multimodal(self, xes, fwd_rtn):
+        row = self._job.loss_log[0]
+        total = _LossFn.apply(self._anchor, self, "total", row[0])
+        return {"total": total, "kl": row[1].clone(), "ll": row[2].clone().reshape(1),
+                "tc": (row[_lib.NM_LOSS_TC] * self.modalities).clone()}
+
+    def pred_recon(self, xes, c, DEVICE, combine):
+        return super().pred_recon(xes, c, DEVICE, self._kernel_combine(combine))
 
 
 class mmJSD(cVAE_multimodal):
@@ -542,6 +668,20 @@ class cVAE_multimodal_endtoend(_HeadBase):
     def _build_tree(self):
         v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
         s, L = self.spec, len(self.spec.hidden)
+        if s.is_dm:                                 # encoder_list.{m}.fc1 ... / decoder_list.{m}.fc_out (cVAE.py:1453-1479)
+            def stack(prefix, layers):
+                mods = []
+                for m in range(s.M):
+                    mod = nn.Module()
+                    for l in layers:
+                        mod.add_module(l, _Holder(weight=v[f"{prefix}.{m}.{l}.weight"], bias=v[f"{prefix}.{m}.{l}.bias"]))
+                    mods.append(mod)
+                return nn.ModuleList(mods)
+            if "weights" in v:
+                self.register_parameter("weights", v["weights"])
+            self.encoder_list = stack("encoder_list", ("fc1", "fc2", "fc_mu", "fc_logvar"))
+            self.decoder_list = stack("decoder_list", ("fc1", "fc2", "fc_out"))
+            return
 
         def enc(m):
             p = s.enc_prefix(m)

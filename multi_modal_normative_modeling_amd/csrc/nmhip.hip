@@ -59,7 +59,6 @@ constexpr int ACT_BYTES = ROWS * LDP * 2;            // 69,632: a saved activati
 constexpr int PATCH_LD = 20;                         // floats: 16 + 4 (conflict-free 16-byte patch writes)
 constexpr int PATCH_FLOATS = 16 * PATCH_LD;          // one wave's 16 x 16 fp32 transposition patch
 constexpr int SPATCH_OFF = 8192;                     // patches inside S (bytes): above the 4 KiB the second x slot runs into S
-constexpr float SLOPE = 0.01f;   // F.leaky_relu default (cVAE.py:167,203)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -89,9 +88,11 @@ struct Ctx {
   float* vec;        // [2][256] fp32 vector slots (biases / logvar_out that travel with a weight image)
   int part, nparts;  // NM_F_SPLIT: this workgroup runs modality `part` of the job (of nparts); -1: the whole job
   int lstep;         // step index inside this launch (hand-off targets)
+  float slope;       // negative slope of the activation (nm_job_t.act_slope)
   float* red;        // [64] reduction scratch
   float* colacc;     // [128] per-column accumulators
   float* rowacc;     // [256] per-row accumulators
+  float* lse;        // [256] logsumexp over the rows of every expert's mu column (mvtCAE total correlation)
   unsigned long long* tlast;   // [8] last stamp per wave (NM_F_TRACE)
   int tid, lane, wave, wm, wn, g, c16;
   int row0;          // first table row of this tile
@@ -197,7 +198,7 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-__device__ __forceinline__ float lrelu(float v, bool nl) { return (nl && v < 0.f) ? v * SLOPE : v; }
+__device__ __forceinline__ float lrelu(float v, bool nl, float slope) { return (nl && v < 0.f) ? v * slope : v; }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
@@ -528,8 +529,10 @@ __device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf
 // [z | c | 1 | 0] rows of the decoder input (cVAE.py:199) into an LDS buffer: the covariate / ones columns from
 // the table's cz block (16-byte pieces, scattered to the unaligned destination with 2-byte LDS stores), zero pad,
 // then the z columns from the latent workspace.
+// (DMVAE family: the last S of the Z latent columns are the modality's private latent = columns [0, S) of its own
+// encoder's mu, `priv`, taken as they are)
 __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_modality_t& md, gcf32 mu_j, gcf32 es, int Z,
-                                         int C, int Zs) {
+                                         int C, int Zs, int S, gcf32 priv) {
   const int wz = wpad(Z + C);
   const float rz = 1.0f / (float)Z;
   const GAS uint16_t* cz = asg(md.cz);
@@ -557,10 +560,14 @@ __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_mod
       }
     }
   }
+  const int Zc = Z - S;                              // shared columns first, then the private ones
 #pragma unroll 4
   for (int e = c.tid; e < ROWS * Z; e += WG) {
     int r = idiv(e, Z, rz), k = e - r * Z;
-    dst[r * LDP + k] = (__bf16)(mu_j[r * Zs + k] + es[r * Zs + k]);
+    const int ks = min(k, max(Zc - 1, 0)), kp = min(max(k - Zc, 0), max(S - 1, 0));
+    const float shared = mu_j[r * Zs + ks] + es[r * Zs + ks];
+    const float v = (k < Zc) ? shared : (S > 0 ? priv[r * Zs + kp] : 0.f);
+    dst[r * LDP + k] = (__bf16)v;
   }
 }
 
@@ -602,7 +609,7 @@ __device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v = acc[t][rt][i] + bv[i];
-        v = (f0 + i < N) ? lrelu(v, act) : (f0 + i == N ? 1.0f : 0.0f);
+        v = (f0 + i < N) ? lrelu(v, act, c.slope) : (f0 + i == N ? 1.0f : 0.0f);
         pk[i] = (__bf16)v;
       }
       *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
@@ -834,7 +841,7 @@ __device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float d = acc[t][rt][i];
-        if (act && !((float)a[i] > 0.f)) d *= SLOPE;
+        if (act && !((float)a[i] > 0.f)) d *= c.slope;
         if (k0 + i >= K) d = 0.f;
         pk[i] = (__bf16)d;
       }
@@ -1060,7 +1067,9 @@ __device__ __forceinline__ Fuse fuse_fwd(const nm_job_t* J, const Lat& L, const 
   for (int m = 0; m < NM_MAX_EXP; ++m) {
     if (m < M) {
       float var = expf(L.lv[m]);
-      float w = (cb == NM_COMBINE_GPOE) ? al[m] / var : 1.0f / var;
+      // POE2V (mvtCAE 'poe', cVAE.py:1782-1783 + 1481-1489): the variances stand where ProductOfExperts2 expects log
+      // variances, so the precisions are exp(-var_m)
+      float w = (cb == NM_COMBINE_POE2V) ? expf(-var) : ((cb == NM_COMBINE_GPOE) ? al[m] / var : 1.0f / var);
       S += w; Smu += L.mu[m] * w;
       sm += L.mu[m]; sv += var;
     }
@@ -1069,7 +1078,9 @@ __device__ __forceinline__ Fuse fuse_fwd(const nm_job_t* J, const Lat& L, const 
   else {
     f.mu = Smu / S; f.var = 1.0f / S;
     if (cb == NM_COMBINE_MOPOE) { f.mu = (sm + f.mu) / (M + 1); f.var = (sv + f.var) / (M + 1); }
+    if (cb == NM_COMBINE_POE2V) f.var = logf(1.0f / S);          // ... and its "logvar" is taken as the joint variance
   }
+  if (J->var_floor > 0.f) f.var = fmaxf(f.var, J->var_floor);   // torch.clamp(variance_multimodal, min=1e-6), cVAE.py:1823
   f.lv = logf(f.var);
   return f;
 }
@@ -1087,10 +1098,30 @@ __device__ __forceinline__ FuseGrad fuse_bwd(const nm_job_t* J, const Lat& L, co
 #pragma unroll
   for (int m = 0; m < NM_MAX_EXP; ++m) {
     if (m < M) {
-      float w = expf(-L.lv[m]) * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);
+      float w = (cb == NM_COMBINE_POE2V) ? expf(-expf(L.lv[m])) : expf(-L.lv[m]) * ((cb == NM_COMBINE_GPOE) ? al[m] : 1.0f);
       S += w; Smu += L.mu[m] * w;
       sv += expf(L.lv[m]);
     }
+  }
+  if (J->var_floor > 0.f) {                        // a clamped joint variance passes no gradient
+    const float var_p0 = 1.0f / S;
+    const float var_u = (cb == NM_COMBINE_MOE) ? sv / M : (cb == NM_COMBINE_MOPOE) ? (sv + var_p0) / (M + 1)
+                        : (cb == NM_COMBINE_POE2V) ? logf(var_p0) : var_p0;
+    if (!(var_u > J->var_floor)) dlv_j = 0.f;
+  }
+  if (cb == NM_COMBINE_POE2V) {
+    // p_m = exp(-v_m), v_m = exp(lv_m); mu_j = sum mu_m p_m / S; u = -log S; lv_j = log u:
+    //   d mu_j / d mu_m = p_m / S,  d mu_j / d lv_m = -(mu_m - mu_j) p_m v_m / S,  d lv_j / d lv_m = v_m p_m / (u S)
+    const float mu_p = Smu / S, u = logf(1.0f / S);
+#pragma unroll
+    for (int m = 0; m < NM_MAX_EXP; ++m) {
+      if (m < M) {
+        const float v = expf(L.lv[m]), r = expf(-v) / S;
+        G.dmu[m] = dmu_j * r;
+        G.dlv[m] = -dmu_j * (L.mu[m] - mu_p) * r * v + dlv_j * r * v / u;
+      }
+    }
+    return G;
   }
   if (cb == NM_COMBINE_MOE) {
 #pragma unroll
@@ -1145,15 +1176,17 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const bool exportf = (c.flags & NM_F_EXPORT) != 0;
   const WsLayout wl = ws_layout(M, L, Z);
   const int Zs = wl.Zs;
-  const float rZ = 1.0f / (float)Z;
   const bool split = c.part >= 0;               // this workgroup runs one modality of the model (NM_F_SPLIT)
   const int part = split ? c.part : 0;
+  const int S = J->n_private, Zc = Z - S;       // DMVAE family: private / shared latent columns (S = 0: all shared)
+  const float rZc = Zc > 0 ? 1.0f / (float)Zc : 0.f;
+  const bool sigm = J->out_kind == 1;           // sigmoid output, ll = -0.5 sum (x - x_hat)^2
   gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m + (int64_t)(step & 1) * M * wl.lat);
   gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m + (int64_t)(step & 1) * M * wl.lat);
   gf32 ws_mu_j = (gf32)(c.ws + wl.mu_j + part * wl.lat);
   gf32 ws_lv_j = (gf32)(c.ws + wl.lv_j + part * wl.lat);
   gf32 ws_es = (gf32)(c.ws + wl.es + part * wl.lat);
-  gf32 ws_dz = (gf32)(c.ws + wl.dz + part * wl.lat);
+  gf32 ws_dz0 = (gf32)(c.ws + wl.dz);            // d z of decoder m at + m * 256 * Zs (one copy per decoder)
   GAS char* ws_enc = c.ws + wl.enc_act;         // activation images [256][LDP], ACT_BYTES each
   GAS char* ws_dec = c.ws + wl.dec_act + (int64_t)part * L * wl.act;
   GAS char* ws_zc = c.ws + wl.zc + part * wl.act;
@@ -1205,13 +1238,55 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       Lt.lv[m] = (m < Me) ? ws_lv_m[((int64_t)m * ROWS + r) * Zs + z] : 0.f;
     }
   };
+  // learnable per-modality loss weights (WeightedDMVAE.weights, cVAE.py:1650, 1693-1697): read once per step, before
+  // any of them is updated
+  // mvtCAE's total-correlation term (cVAE.py:1862-1869): tc = - sum_z mean_m logsumexp_rows(mu_m[:, z]) -- the joint
+  // posterior's half of it is a scalar minus its own mean, identically zero.  One wave per (expert, latent column):
+  // max and sum over the rows by shuffles (fixed order), kept in LDS for the backward pass.
+  float tc = 0.f;
+  if (J->tc_weight != 0.f) {
+    relaunder(c);
+    for (int col = c.wave; col < Me * Z; col += NWAVES) {
+      const int m = col / Z, z = col - m * Z;
+      float v[4], mx = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = c.lane + 64 * k;
+        const float x = ws_mu_m[((int64_t)m * ROWS + min(r, c.nrows - 1)) * Zs + z];
+        v[k] = (r < c.nrows) ? x : -3.0e38f;
+        mx = fmaxf(mx, v[k]);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sx += (c.lane + 64 * k < c.nrows) ? expf(v[k] - mx) : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sx += __shfl_xor(sx, o, 64);
+      if (c.lane == 0) c.lse[col] = mx + logf(sx);
+    }
+    lds_barrier();
+    for (int z = 0; z < Z; ++z) {
+      float sm_ = 0.f;
+      for (int m = 0; m < Me; ++m) sm_ += c.lse[m * Z + z];
+      tc -= sm_ / (float)Me;
+    }
+  }
+  // (weights[m] is read at the start of decoder m and updated at its end, by that decoder only; their sum, the
+  //  weight of the KL term, is formed here, before any of them moves)
+  float kl_w = J->kl_weight;
+  if (J->w_off >= 0) {
+    kl_w = 0.f;
+    for (int m = 0; m < M; ++m) kl_w += asg(J->params)[J->w_off + m];
+  }
   float kl_part = 0.f;
   relaunder(c);
+  // shared latent column z = head column S + z
 #pragma unroll 2
-  for (int e = c.tid; e < ROWS * Z; e += WG) {
-    int r = idiv(e, Z, rZ), z = e - r * Z;
+  for (int e = c.tid; e < ROWS * Zc; e += WG) {
+    int r = idiv(e, Zc, rZc), z = e - r * Zc;
     Lat Lt;
-    load_lat(Lt, r, z);
+    load_lat(Lt, r, S + z);
     Fuse f = fuse_fwd(J, Lt, al);
     float ep = J->eps ? asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + z]
                       : randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)z);
@@ -1221,7 +1296,6 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     ws_mu_j[r * Zs + z] = f.mu;
     ws_lv_j[r * Zs + z] = f.lv;
     ws_es[r * Zs + z] = es;
-    ws_dz[r * Zs + z] = 0.f;
     if (r < c.nrows) {
       kl_part += -0.5f * (1.0f + f.lv - f.mu * f.mu - expf(f.lv));
       if (exportf && part == 0) {
@@ -1247,9 +1321,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const int Kd0 = Z + C;
     if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
     // z | c | 1: built by the first decoder; the others reuse it when all tables carry the same covariates
-    const bool reuse_zc = J->shared_cov && M > 1 && !split;
+    const bool reuse_zc = J->shared_cov && M > 1 && !split && S == 0;
     if (m == 0 || !reuse_zc) {
-      build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs);
+      build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs, S, ws_mu_m + (int64_t)min(m, Me - 1) * ROWS * Zs);
       lds_barrier();
       if (bwd || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P);
     } else {
@@ -1291,7 +1365,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     // read once, outside the per-lane selects below: a descriptor load inside `cond ? load * x : 0` becomes a
     // lane-divergent branch, and register spills placed around such branches are not safe with this compiler
     // (tools/check_spill_exec.py)
-    const float llw_b = J->ll_weight * c.inv_b;
+    const float ll_w = (J->w_off >= 0) ? asg(J->params)[J->w_off + m] : J->ll_weight;
+    const float llw_b = ll_w * c.inv_b;
     for (int ch = 0; ch < nck; ++ch) {
       relaunder(c);
       const int d0 = ch * OCH;
@@ -1353,10 +1428,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         // per column: q = sum_r diff^2 (valid rows only).  Then  NLL = sum_d [0.5 e^{-s} q + n (0.5 s + log sqrt(2 pi))]
         // and d(-LL)/d s_d = (0.5 n - 0.5 e^{-s} q) / B: one masked square-accumulate per element instead of
         // evaluating both sums element by element.
+        // (sigmoid / squared-error output, cVAE.py:1478, 1560: x_hat = sigmoid(a), ll = -0.5 sum (x - x_hat)^2 -- the same
+        //  epilogue with unit precision, no logvar_out, and the sigmoid's derivative on the way back)
         float inv[4], colq[4], coef[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          inv[i] = expf(-sv[i]);
+          inv[i] = sigm ? 1.0f : expf(-sv[i]);
           colq[i] = 0.f;
           coef[i] = (dg0 + i < D) ? llw_b * inv[i] : 0.f;                      // d total / d x_hat = coef * diff
         }
@@ -1366,7 +1443,16 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           const int r = c.wm * WROWS + rt * 16 + c.c16;
           const bool rv = r < c.nrows;
           nvalid += rv ? 1 : 0;
-          acc[rt] += bo;                                                       // x_hat
+          acc[rt] += bo;                                                       // x_hat (pre-sigmoid with out_kind 1)
+          float dsig[4] = {1.f, 1.f, 1.f, 1.f};
+          if (sigm) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float sg = 1.0f / (1.0f + expf(-acc[rt][i]));
+              acc[rt][i] = sg;
+              dsig[i] = sg * (1.0f - sg);
+            }
+          }
           bf16x4 pk;
           f32x4 ex = {0.f, 0.f, 0.f, 0.f};
           if (md.dloc_extra)               // extra loss gradient on x_hat (regression head)
@@ -1378,7 +1464,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             const float diff = rv ? acc[rt][i] - xin[rt][i] : 0.f;
             colq[i] = fmaf(diff, diff, colq[i]);
             const bool dv = dg0 + i < D;
-            pk[i] = (__bf16)(diff * (coef[i] + (dv ? rc : 0.f)) + ((rv && dv) ? ex[i] : 0.f));
+            pk[i] = (__bf16)((diff * (coef[i] + (dv ? rc : 0.f)) + ((rv && dv) ? ex[i] : 0.f)) * dsig[i]);
           }
           if (bwd) *reinterpret_cast<bf16x4*>(Dq + r * LDX + dl0) = pk;
         }
@@ -1387,7 +1473,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         for (int i = 0; i < 4; ++i) {
           const bool dv = dg0 + i < D;
           const float hq = 0.5f * inv[i] * colq[i];
-          nll_part += dv ? hq + (float)nvalid * (0.5f * sv[i] + LOG_SQRT_2PI) : 0.f;
+          nll_part += dv ? hq + (sigm ? 0.f : (float)nvalid * (0.5f * sv[i] + LOG_SQRT_2PI)) : 0.f;
           colsum[i] = dv ? 0.5f * (float)nvalid - hq : 0.f;
         }
         if (exportf && dg0 < xp) {           // exports share the fp32 table's row pitch: one 16-byte store each
@@ -1436,8 +1522,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       if (adam_on && c.wave + NWAVES < wg_units(Go)) wg_request(c, Go, c.wave + NWAVES, pm_b);
 #endif
       // d logvar_out for this chunk (master + the copy that travels with the chunk's image)
-      if (c.tid < valid)
-        apply_grad(c, md.logvar_out + d0 + c.tid, J->ll_weight * c.colacc[c.tid] * c.inv_b,
+      if (c.tid < valid && !sigm)
+        apply_grad(c, md.logvar_out + d0 + c.tid, ll_w * c.colacc[c.tid] * c.inv_b,
                    (GAS float*)(oblob + (int64_t)ch * OBLOB_BYTES + OIMG_BYTES) + OCH + c.tid);
       // dgrad into the last hidden activation: accg[k][r] += sum_d Dq[r][d] Wo[d0 + d][k], weights from the slot
       dgrad_tile(c, accg, Dq, LDX, 0, Wc, LDP, OCH / 32);
@@ -1453,7 +1539,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       prof(c, PH_OUT_WGRAD);
     }
     float nll = block_sum(c, nll_part);
-    const float ll_this = -nll * c.inv_b;           // compute_ll: sum over ROI, mean over rows
+    float ll_this = -nll * c.inv_b;                 // compute_ll: sum over ROI, mean over rows
+    if (J->w_off >= 0) {                            // WeightedDMVAE: ll_i * weights[i]; d total / d weights[i] = KL - ll_i
+      if (c.tid == 0 && bwd) apply_grad(c, J->w_off + m, kl - ll_this, nullptr);
+      ll_this *= ll_w;
+    }
     ll_sum += ll_this;
     if (c.tid == 0 && J->loss_log)
       asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_LL_M + m] = ll_this;
@@ -1493,7 +1583,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         finish_delta(c, acc, c.Q, Kin, nl);
         lds_barrier();
       } else {
-        // d z: accumulate over decoders (fixed element -> thread ownership, no race)
+        // d z of this decoder
         const int ntk = wpad(Kin) / 16;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1504,8 +1594,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
               int r = c.wm * WROWS + rt * 16 + c.c16;
-              GAS f32x4* p = (GAS f32x4*)(ws_dz + r * Zs + k0);    // columns >= Z of the row are never read
-              *p = *p + acc[t][rt];
+              // decoder m's own copy (columns >= Z of the row are never read); the sum over the decoders is formed
+              // where it is used, in decoder order
+              *(GAS f32x4*)(ws_dz0 + (int64_t)m * ROWS * Zs + r * Zs + k0) = acc[t][rt];
             }
           }
         }
@@ -1525,33 +1616,33 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       ll_sum = 0.f;
       for (int m = 0; m < M; ++m) ll_sum += row[NM_LOSS_LL_M + m];
     }
-    row[NM_LOSS_KL] = J->kl_weight * kl;
+    const float llw_tot = (J->w_off >= 0) ? 1.0f : J->ll_weight;        // (weighted per modality already)
+    row[NM_LOSS_KL] = kl_w * kl;
     row[NM_LOSS_LL] = ll_sum;
-    row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
+    row[NM_LOSS_TC] = tc;
+    row[NM_LOSS_TOTAL] = kl_w * kl - llw_tot * ll_sum + J->tc_weight * tc;
   }
   if (!bwd) return;
   if (split && part >= Me) return;                // a decoder-only part has no encoder to differentiate
   prof(c, PH_ALPHA);
   // d z = sum over the decoders, in decoder order (single workgroup: accumulated in place in that order)
+  // d z of shared column z = sum over the decoders, in decoder order
   auto load_dz = [&](int r, int z) {
-    float d = ws_dz[r * Zs + z];
-    if (split) {
-      gcf32 base = (gcf32)(c.ws + wl.dz);
-      d = base[r * Zs + z];
-      for (int q = 1; q < M; ++q) d += base[(int64_t)q * ROWS * Zs + r * Zs + z];
-    }
+    float d = ws_dz0[r * Zs + z];
+    for (int q = 1; q < M; ++q) d += ws_dz0[(int64_t)q * ROWS * Zs + r * Zs + z];
     return d;
   };
 
   // ================= fusion backward: alpha gradients (gPoE) =================
   const bool fused = !(Me == 1 && J->single_bypass);
-  const float klw = J->kl_weight * c.inv_b;
+  const float klw = kl_w * c.inv_b;
+  const float tcw = J->tc_weight / (float)Me;     // (the softmax over the rows is normalised: no 1 / B)
   gbf16 ws_fz = (gbf16)ws_zc;                     // the (dead) z|c slot, legacy [256][PW] layout
   // With several experts the fusion backward (8 exponentials per element) is evaluated ONCE: the deltas of every
   // expert go side by side into Q (expert m in columns [m 2Zs, (m+1) 2Zs) = [d mu_m | d logvar_m]), from there into
   // the (dead) z|c slot of the workspace, and each encoder's backward below starts from a 16-byte copy of its
   // columns.  Falls back to one evaluation per encoder when the deltas do not fit in 128 columns.
-  const bool once = fused && Me >= 2 && Me * 2 * Zs <= PW && !split;
+  const bool once = fused && Me >= 2 && Me * 2 * Zs <= PW && !split && S == 0;
   // (split: the alpha sums ride on the part's own evaluation of the fusion backward, below)
   if (once || (fused && J->combine == NM_COMBINE_GPOE && !split)) {
     relaunder(c);
@@ -1565,10 +1656,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         c.Q[r * LDP + blk * Zs + Z + k] = (__bf16)0.0f;
       }
     }
-    for (int e = c.tid; e < ROWS * Z; e += WG) {
-      int r = idiv(e, Z, rZ), z = e - r * Z;
+    for (int e = c.tid; e < ROWS * Zc; e += WG) {
+      int r = idiv(e, Zc, rZc), z = e - r * Zc;
       Lat Lt;
-      load_lat(Lt, r, z);
+      load_lat(Lt, r, S + z);
       float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
       if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
       float dmu_j = dz + klw * mj;
@@ -1579,6 +1670,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       for (int m = 0; m < NM_MAX_EXP; ++m) {
         dal[m] += rv ? G.dal[m] : 0.f;
         if (once && m < Me) {
+          // d (tc_weight tc) / d mu_m[r][z] = -(tc_weight / Me) softmax over the rows
+          if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
           c.Q[r * LDP + m * 2 * Zs + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
           c.Q[r * LDP + m * 2 * Zs + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
         }
@@ -1632,19 +1725,28 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         int k = (j < Zs - Z) ? Z + j : Zs + Z + (j - (Zs - Z));
         c.P[r * LDP + k] = (__bf16)0.0f;
       }
+      // private columns (DMVAE family): d mu_m[:, i] = d z of THIS decoder's private input column; logvar unused
+      for (int e = c.tid; e < ROWS * S; e += WG) {
+        const int r = e / S, i = e - r * S;
+        const float d = ws_dz0[(int64_t)m * ROWS * Zs + r * Zs + Zc + i];
+        c.P[r * LDP + i] = (__bf16)(r < c.nrows ? d : 0.f);
+        c.P[r * LDP + Zs + i] = (__bf16)0.0f;
+      }
 #pragma unroll 2
-      for (int e = c.tid; e < ROWS * Z; e += WG) {
-        int r = idiv(e, Z, rZ), z = e - r * Z;
+      for (int e = c.tid; e < ROWS * Zc; e += WG) {
+        int r = idiv(e, Zc, rZc), z = e - r * Zc;
         Lat Lt;
-        load_lat(Lt, r, z);
+        load_lat(Lt, r, S + z);
         float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
         if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
         float dmu_j = dz + klw * mj;
         float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
         FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
         const bool rv = r < c.nrows;
-        c.P[r * LDP + z] = (__bf16)(rv ? pick(G.dmu, m) : 0.f);
-        c.P[r * LDP + Zs + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
+        float dmu_m = pick(G.dmu, m);
+        if (tcw != 0.f) dmu_m -= tcw * expf(pick(Lt.mu, m) - c.lse[m * Z + z]);
+        c.P[r * LDP + S + z] = (__bf16)(rv ? dmu_m : 0.f);
+        c.P[r * LDP + Zs + S + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
 #pragma unroll
         for (int q = 0; q < NM_MAX_EXP; ++q) dal_s[q] += rv ? G.dal[q] : 0.f;
       }
@@ -1753,7 +1855,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 }
 
 // ----------------------------------------------------------------------------------------------
-constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + STAGE_FLOATS * 4 + 2 * VEC_BYTES + (64 + 128 + 256 + 16) * 4;
+constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + STAGE_FLOATS * 4 + 2 * VEC_BYTES + (64 + 128 + 256 + 256 + 16) * 4;
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 static_assert(XIMG_BYTES + OBLOB_BYTES + NWAVES * PATCH_FLOATS * 4 <= ACT_BYTES, "output-chunk layout of Q");
 static_assert(2 * XIMG_BYTES - ACT_BYTES <= SPATCH_OFF && SPATCH_OFF + NWAVES * PATCH_FLOATS * 4 <= STAGE_FLOATS * 4, "S layout");
@@ -1766,7 +1868,8 @@ __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
   c.red = c.vec + 2 * (VEC_BYTES / 4);
   c.colacc = c.red + 64;
   c.rowacc = c.colacc + 128;
-  c.tlast = reinterpret_cast<unsigned long long*>(c.rowacc + 256);
+  c.lse = c.rowacc + 256;
+  c.tlast = reinterpret_cast<unsigned long long*>(c.lse + 256);
 }
 
 template <bool SCALAR_TR>
@@ -1788,6 +1891,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   c.job = J;
   c.part = part;
   c.nparts = nparts;
+  c.slope = J->act_slope;
   carve_lds(c, smem);
   relaunder(c);
   c.flags = flags;
@@ -1810,8 +1914,11 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     c.nrows = min(ROWS, J->n_rows - c.row0);
     c.inv_b = 1.0f / (float)c.nrows;
     // bias corrections in double, as torch.optim.Adam computes them on the host
-    const double tt = (double)(J->adam_off + (int64_t)s + 1);
-    c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
+    const int64_t t_opt = J->adam_off + (int64_t)s + 1;
+    const double tt = (double)t_opt;
+    // learning rate of this optimizer step: the schedule table (param_group['lr'] = clr per step) or the constant
+    const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
+    c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
     if (flags & NM_F_PROFILE) c.t_last = clock64();
     if (flags & 64) c.tlast[threadIdx.x >> 6] = clock64();
@@ -1900,7 +2007,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   carve_lds(c, smem);
   relaunder(c);
   c.flags = flags & ~(NM_F_PROFILE | NM_F_TRACE);
-  c.part = -1; c.nparts = 1; c.lstep = 0;
+  c.part = -1; c.nparts = 1; c.lstep = 0; c.slope = J->act_slope;
   c.t_last = 0;
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -1909,8 +2016,10 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   c.nrows = min(ROWS, J->n_rows - c.row0);
   if (c.nrows <= 0) return;
   c.inv_b = 1.0f / (float)c.nrows;
-  const double tt = (double)(J->adam_off + (int64_t)step + 1);
-  c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
+  const int64_t t_opt = J->adam_off + (int64_t)step + 1;
+  const double tt = (double)t_opt;
+  const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
+  c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
   c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
   const bool bwd = (flags & NM_F_BACKWARD) != 0;
   const int M = experts(J);
@@ -2128,7 +2237,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   carve_lds(c, smem);
   relaunder(c);
   c.flags = flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS);
-  c.part = -1; c.nparts = 1; c.lstep = 0;
+  c.part = -1; c.nparts = 1; c.lstep = 0; c.slope = J->act_slope;
   c.t_last = 0;
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -2137,8 +2246,10 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   c.nrows = min(ROWS, J->n_rows - c.row0);
   if (c.nrows <= 0) return;
   c.inv_b = 1.0f / (float)c.nrows;
-  const double tt = (double)(J->adam_off + (int64_t)step + 1);
-  c.step_size = (float)((double)J->lr / (1.0 - pow((double)J->beta1, tt)));
+  const int64_t t_opt = J->adam_off + (int64_t)step + 1;
+  const double tt = (double)t_opt;
+  const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
+  c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
   c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
   const bool train = J->cls_train != 0;
   const bool bwd = (flags & NM_F_BACKWARD) != 0 && train && J->labels != nullptr;
@@ -2526,7 +2637,7 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
     for (int i = threadIdx.x; i < md.D; i += blockDim.x) {
       float* vb = (float*)(wsh + md.out_s + (int64_t)(i / OCH) * OBLOB_BYTES + OIMG_BYTES);
       vb[i % OCH] = prm[md.out_b + i];
-      vb[OCH + i % OCH] = prm[md.logvar_out + i];
+      if (J->out_kind == 0) vb[OCH + i % OCH] = prm[md.logvar_out + i];
     }
   }
 }
@@ -2710,6 +2821,7 @@ const char* nm_status_string(int status) {
     case -6: return "latent + c_dim exceeds NM_MAX_WIDTH";
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
+    case -18: return "out_kind must be 0 or 1, 0 <= n_private <= Z, and a private latent needs an encoder per decoder";
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
@@ -2732,7 +2844,9 @@ int nm_validate_job(const nm_job_t* j) {
     if (j->H[i] < 1 || j->H[i] > NM_MAX_WIDTH) return -4;
   if (j->Z < 1 || j->Z > NM_MAX_LATENT) return -5;
   if (j->Z + j->C > NM_MAX_WIDTH) return -6;
-  if (j->combine < 0 || j->combine > NM_COMBINE_MOPOE) return -9;
+  if (j->combine < 0 || j->combine > NM_COMBINE_POE2V) return -9;
+  if (j->out_kind < 0 || j->out_kind > 1 || j->n_private < 0 || j->n_private > j->Z) return -18;
+  if (j->n_private > 0 && j->M_enc != 0 && j->M_enc != j->M) return -18;      // a private latent needs the modality's own encoder
   if (j->n_rows < 1 || j->loss_cap < 1 || j->eps_cap < 1) return -14;       // modulo divisors / batch count in the kernel
   if (!j->wsh) return -15;
   for (int m = 0; m < j->M; ++m) {
@@ -2744,7 +2858,8 @@ int nm_validate_job(const nm_job_t* j) {
       if ((md.enc_b[i] | md.dec_b[i]) & 3) return -10;
       if ((md.enc_w[i] | md.dec_w[i]) & 255) return -10;
     }
-    if ((md.mu_b | md.lv_b | md.logvar_out | md.out_b) & 3) return -10;
+    if ((md.mu_b | md.lv_b | md.out_b) & 3) return -10;
+    if (j->out_kind == 0 && (md.logvar_out < 0 || (md.logvar_out & 3))) return -10;
     if ((md.mu_w | md.lv_w | md.out_w) & 255) return -10;
   }
   if (j->cls_classes > 0) {

@@ -97,8 +97,8 @@ class Job:
         if len(tables) != spec.M:
             raise ValueError(f"need {spec.M} tables, got {len(tables)}")
         for m, t in enumerate(tables):
-            if t.D != spec.input_dims[m] or t.C != spec.c_dim:
-                raise ValueError(f"table {m}: D={t.D}, C={t.C} do not match the model ({spec.input_dims[m]}, {spec.c_dim})")
+            if t.D != spec.input_dims[m] or t.C != spec.net_c_dim:
+                raise ValueError(f"table {m}: D={t.D}, C={t.C} do not match the model ({spec.input_dims[m]}, {spec.net_c_dim})")
             if t.N != tables[0].N:
                 raise ValueError("all modalities must hold the same subjects (rows)")
         combine_l = combine.lower()
@@ -115,8 +115,22 @@ class Job:
         self.adam_v = torch.zeros_like(self.params)
         self.grads = torch.zeros_like(self.params)
         self.lr, self.betas, self.adam_eps = float(lr), (float(betas[0]), float(betas[1])), float(adam_eps)
-        # cVAE_multimodal adds KL once per modality (cVAE.py:1189-1195); class cVAE once (cVAE.py:497-500)
-        self.kl_weight = float(spec.M if kl_weight is None else kl_weight)
+        # cVAE_multimodal adds KL once per modality (cVAE.py:1189-1195); class cVAE once (cVAE.py:497-500); the DMVAE
+        # family: once per modality times beta (1.0, mmVAEPlus 0.05; cVAE.py:1507, 1911, 1570)
+        dm_beta = {"dmvae": 1.0, "weighted_dmvae": 1.0, "mmvaeplus": 0.05}.get(spec.kind, 1.0)
+        self.kl_weight = float(spec.M * dm_beta if kl_weight is None else kl_weight)
+        if spec.is_dm:
+            single_bypass = False                     # ProductOfExperts2 is always evaluated (cVAE.py:1547)
+        # mvtCAE (cVAE.py:1754-1893): no single-expert bypass, 'poe' = ProductOfExperts2 fed with variances, joint variance
+        # clamped at 1e-6, total = sum_i [kl + 1e-5 ll_i + beta tc] with beta = 1e-4 (the log-likelihood enters with a PLUS)
+        self.var_floor, self.tc_weight = 0.0, 0.0
+        if spec.kind == "mvtcae":
+            single_bypass = False
+            self.var_floor, self.tc_weight = 1e-6, spec.M * 1e-4
+            if combine.lower() == "poe":
+                self.combine = "poe2v"
+            if ll_weight == 1.0:
+                ll_weight = -1e-5
         self.kmods = spec.kernel_modalities()         # decoders the kernel runs: (table, has_encoder, prefix)
         self.dz_extra: Optional[torch.Tensor] = None  # d L_extra / d z          [rows_alloc, Z]
         self.dloc_extra: List[Optional[torch.Tensor]] = [None] * len(self.kmods)   # d L_extra / d x_hat [rows_alloc, x_pitch]
@@ -139,6 +153,7 @@ class Job:
         self.loss_log = torch.zeros(self.loss_cap, _lib.NM_LOSS_STRIDE, dtype=torch.float32, device=dev)
         self.eps: Optional[torch.Tensor] = None
         self.eps_cap = 1
+        self.lr_table: Optional[torch.Tensor] = None   # fp64 [n]: learning rate of optimizer step t = lr_table[(t - 1) % n]
         self._ws = None
         self._ws_tiles = 0
         self._version = 0                # bumped whenever the descriptor would change
@@ -221,6 +236,13 @@ class Job:
         """Call after changing tables / step / t / hyper-parameters by hand: forces a descriptor re-upload."""
         self._version += 1
 
+    def set_lr_table(self, lrs):
+        """Per-step learning rates (optimizer step t, 1-based, runs at lrs[(t - 1) % len]): the schedules that really
+        reach the optimizer in the reference (`param_group['lr'] = clr`, multimodal_kfold_cvae_nmmlp.py:376-381;
+        prep.cyclic_lr builds that one).  None: the constant lr."""
+        self.lr_table = None if lrs is None else torch.as_tensor(np.asarray(lrs, dtype=np.float64)).to(self.device).contiguous()
+        self._version += 1
+
     def set_eps(self, eps: Optional[torch.Tensor]):
         """Explicit reparameterisation draws [n_steps, 256, Z] (parity mode); None = in-kernel generator."""
         self._version += 1
@@ -259,19 +281,27 @@ class Job:
     # -- descriptor ----------------------------------------------------------------------------
     def struct(self) -> _lib.NmJob:
         s, j = self.spec, _lib.NmJob()
-        j.M, j.M_enc, j.C, j.L, j.Z = len(self.kmods), s.M, s.c_dim, len(s.hidden), s.latent
+        j.M, j.M_enc, j.C, j.L, j.Z = len(self.kmods), s.M, s.net_c_dim, len(s.hidden), s.latent
+        # DMVAE family: ReLU, sigmoid / squared-error output, private latent columns, learnable loss weights
+        j.act_slope = 0.0 if s.is_dm else 0.01
+        j.out_kind = 1 if s.is_dm else 0
+        j.n_private = s.n_private
+        j.w_off = self.layout.offsets["weights"] if s.kind == "weighted_dmvae" else -1
+        j.var_floor, j.tc_weight = self.var_floor, self.tc_weight
         for i, h in enumerate(s.hidden):
             j.H[i] = h
         j.combine = _lib.NM_COMBINE[self.combine]
         j.single_bypass = 1 if self.single_bypass else 0
         j.n_rows = self.tables[0].N
-        j.non_linear = 1 if s.non_linear else 0
+        j.non_linear = 1 if (s.non_linear or s.is_dm) else 0        # (torch.relu unconditionally, cVAE.py:1462-1463)
         j.dephase = int(self.dephase_sleeps)
         k0 = self.tables[0].c_key
         j.shared_cov = 1 if (k0 is not None and all(t.c_key == k0 for t in self.tables)) else 0
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
         j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
         j.adam_off = self.t - self.step
+        j.lr_table = self.lr_table.data_ptr() if self.lr_table is not None else None
+        j.lr_cap = int(self.lr_table.numel()) if self.lr_table is not None else 0
         j.kl_weight, j.ll_weight = self.kl_weight, self.ll_weight
         j.params, j.adam_m, j.adam_v = self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
         j.grads = self.grads.data_ptr()

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 
+DM_KINDS = ("dmvae", "weighted_dmvae", "mmvaeplus")
 ALIGN = 4   # floats
 TILE = 16   # weight matrices are stored as TILE x TILE tiles (wt_off() in nmhip.hip)
 REGRESSOR_WIDTHS = (128, 64, 1)   # cVAE.py:2249-2253
@@ -33,7 +34,10 @@ class ModelSpec:
     c_dim: int
     non_linear: bool = True
     # "single" = class cVAE, "multimodal" = cVAE_multimodal, "regression" = cVAE_multimodal_regression (trunk),
-    # "endtoend" = cVAE_multimodal_endtoend (trunk: shared encoders + health / disease decoder banks)
+    # "endtoend" = cVAE_multimodal_endtoend (trunk: shared encoders + health / disease decoder banks),
+    # "mvtcae" = mvtCAE (cVAE.py:1754-1893): cVAE_multimodal's modules with its own fusion quirk, variance clamp and loss;
+    # "dmvae" / "weighted_dmvae" / "mmvaeplus" = the DMVAE family (cVAE.py:1491-1747, 1895-2002): covariate-free ReLU
+    # encoders, sigmoid decoders with a squared-error likelihood, the first min(c_dim, latent) latent columns private
     kind: str = "multimodal"
     # end-to-end model only: hidden widths of the Classifier (cVAE.py:2004-2018); () = trunk without a classifier
     classifier_layers: Sequence[int] = ()
@@ -42,6 +46,20 @@ class ModelSpec:
     @property
     def M(self) -> int:
         return len(self.input_dims)
+
+    @property
+    def is_dm(self) -> bool:
+        return self.kind in DM_KINDS
+
+    @property
+    def net_c_dim(self) -> int:
+        """Covariate width the networks see: the DMVAE family ignores c (VariationalEncoder / Decoder take x / z only)."""
+        return 0 if self.is_dm else self.c_dim
+
+    @property
+    def n_private(self) -> int:
+        """DMVAE family: s_dim = c_dim (cVAE.py:1506), mu[:, :s_dim] of a [B, latent] tensor."""
+        return min(self.c_dim, self.latent) if self.is_dm else 0
 
     def validate(self):
         n_dec = self.M * (2 if self.kind == "endtoend" else 1)
@@ -53,8 +71,10 @@ class ModelSpec:
             raise ValueError(f"hidden widths must be 1..{_lib.NM_MAX_WIDTH}, got {list(self.hidden)}")
         if not (1 <= self.latent <= _lib.NM_MAX_LATENT):
             raise ValueError(f"latent_dim must be 1..{_lib.NM_MAX_LATENT}, got {self.latent}")
-        if self.latent + self.c_dim > _lib.NM_MAX_WIDTH:
+        if self.latent + self.net_c_dim > _lib.NM_MAX_WIDTH:
             raise ValueError(f"latent_dim + c_dim must be <= {_lib.NM_MAX_WIDTH}")
+        if self.is_dm and len(self.hidden) != 2:
+            raise ValueError("the DMVAE family has exactly two hidden layers (hidden_dims[0], hidden_dims[1])")
         if len(self.classifier_layers) > _lib.NM_MAX_CLS or any(w < 1 or w > 128 for w in self.classifier_layers):
             raise ValueError(f"classifier_layers: at most {_lib.NM_MAX_CLS} widths in 1..128, got {list(self.classifier_layers)}")
         if self.classifier_layers and not (2 <= self.num_classes <= _lib.NM_MAX_CLASSES):
@@ -62,12 +82,12 @@ class ModelSpec:
 
     # encoder / decoder layer sizes exactly as the reference computes them
     def enc_sizes(self, m: int) -> List[int]:
-        return [self.input_dims[m] + self.c_dim] + list(self.hidden) + [self.latent]      # cVAE.py:153
+        return [self.input_dims[m] + self.net_c_dim] + list(self.hidden) + [self.latent]      # cVAE.py:153
 
     def dec_sizes(self, m: int) -> List[int]:
         hd = (list(self.hidden) + [self.latent])[::-1]                                    # cVAE.py:183
         sizes = hd + [self.input_dims[m]]
-        sizes[0] = hd[0] + self.c_dim                                                     # cVAE.py:188
+        sizes[0] = hd[0] + self.net_c_dim                                                 # cVAE.py:188
         return sizes
 
     def enc_prefix(self, m: int) -> str:
@@ -112,10 +132,23 @@ def tensor_table(spec: ModelSpec) -> List[Tuple[str, Tuple[int, ...]]]:
         out.append((f"{p}decoder_mean_layer.weight", (s[-1], s[-2])))
         out.append((f"{p}decoder_mean_layer.bias", (s[-1],)))
 
-    if spec.kind == "single":
+    if spec.is_dm:                           # cVAE.py:1453-1479; a module's own parameter (`weights`) precedes its children's
+        if spec.kind == "weighted_dmvae":
+            out.append(("weights", (spec.M,)))
+        for m in range(spec.M):
+            s = spec.enc_sizes(m)
+            for l, (n_out, n_in) in (("fc1", (s[1], s[0])), ("fc2", (s[2], s[1])), ("fc_mu", (s[3], s[2])), ("fc_logvar", (s[3], s[2]))):
+                out.append((f"encoder_list.{m}.{l}.weight", (n_out, n_in)))
+                out.append((f"encoder_list.{m}.{l}.bias", (n_out,)))
+        for m in range(spec.M):
+            s = spec.dec_sizes(m)
+            for l, (n_out, n_in) in (("fc1", (s[1], s[0])), ("fc2", (s[2], s[1])), ("fc_out", (s[3], s[2]))):
+                out.append((f"decoder_list.{m}.{l}.weight", (n_out, n_in)))
+                out.append((f"decoder_list.{m}.{l}.bias", (n_out,)))
+    elif spec.kind == "single":
         enc(0)
         dec(0)
-    elif spec.kind == "multimodal":
+    elif spec.kind in ("multimodal", "mvtcae"):      # mvtCAE registers the same modules in the same order (cVAE.py:1775-1777)
         for m in range(spec.M):
             out.append((f"alpha_m_list.{m}", (1,)))
         for m in range(spec.M):
@@ -271,7 +304,9 @@ class ParamLayout:
         out: Dict[str, torch.Tensor] = {}
         for n in self.names:
             shape = self.shapes[n]
-            if n.endswith("logvar_out"):
+            if n == "weights":                         # torch.abs(torch.randn(modalities)), cVAE.py:1650
+                out[n] = torch.randn(shape, generator=g).abs()
+            elif n.endswith("logvar_out"):
                 out[n] = torch.full(shape, -3.0)
             elif len(shape) == 1 and n.endswith((".weight", ".running_var")):      # BatchNorm1d defaults
                 out[n] = torch.ones(shape)
@@ -293,6 +328,16 @@ class ParamLayout:
         spec, o = self.spec, self.offsets
         m, has_enc, dp = spec.kernel_modalities()[j]
         ep = spec.enc_prefix(m)
+        if spec.is_dm:
+            md.enc_w[0], md.enc_b[0] = o[f"{ep}fc1.weight"], o[f"{ep}fc1.bias"]
+            md.enc_w[1], md.enc_b[1] = o[f"{ep}fc2.weight"], o[f"{ep}fc2.bias"]
+            md.mu_w, md.mu_b = o[f"{ep}fc_mu.weight"], o[f"{ep}fc_mu.bias"]
+            md.lv_w, md.lv_b = o[f"{ep}fc_logvar.weight"], o[f"{ep}fc_logvar.bias"]
+            md.dec_w[0], md.dec_b[0] = o[f"{dp}fc1.weight"], o[f"{dp}fc1.bias"]
+            md.dec_w[1], md.dec_b[1] = o[f"{dp}fc2.weight"], o[f"{dp}fc2.bias"]
+            md.out_w, md.out_b = o[f"{dp}fc_out.weight"], o[f"{dp}fc_out.bias"]
+            md.logvar_out, md.alpha = -1, -1
+            return
         for i in range(len(spec.hidden)):
             md.enc_w[i] = o[f"{ep}encoder_layers.{i}.weight"] if has_enc else 0
             md.enc_b[i] = o[f"{ep}encoder_layers.{i}.bias"] if has_enc else 0

@@ -103,6 +103,22 @@ def generate_kfold_ids(iid_first: np.ndarray, iid_other: np.ndarray, oversample_
     return out
 
 
+def cyclic_lr(n_steps: int, n_samples: int, batch_size: int = 256, base_lr: float = 1e-6, max_lr: float = 5e-5,
+              gamma: float = 0.98) -> np.ndarray:
+    """The triangular cyclic learning rate with per-cycle decay that multimodal_kfold_cvae_nmmlp.py:357-381 assigns to
+    `param_group['lr']` before every step (the one place in the reference where the schedule reaches Adam):
+    step_size = 2 ceil(n / batch); cycle = floor(1 + gs / (2 step_size)); x = |gs / step_size - 2 cycle + 1|;
+    clr = base + (max - base) max(0, 1 - x) gamma^cycle, for global_step gs = 1..n_steps (fp64, as numpy forms it)."""
+    step_size = 2 * np.ceil(n_samples / batch_size)
+    out = np.empty(n_steps, dtype=np.float64)
+    for i in range(n_steps):
+        gs = i + 1
+        cycle = np.floor(1 + gs / (2 * step_size))
+        x_lr = np.abs(gs / step_size - 2 * cycle + 1)
+        out[i] = base_lr + (max_lr - base_lr) * max(0, 1 - x_lr) * (gamma ** cycle)
+    return out
+
+
 def rows_of_ids(table_iid: np.ndarray, ids: np.ndarray) -> np.ndarray:
     """Row indices of `pd.merge(table, ids_df, on='IID')` for a table with unique IIDs (utils.py:112-140): the merge
     keeps the table's row order and repeats a row once per occurrence of its IID in `ids` (bootstrap duplicates)."""

@@ -97,7 +97,7 @@ class DeviceCohort:
             out.append(self.table(m, rows, center, scale, c))
         return out
 
-    def fold_tables_cached(self, key, modalities: Sequence[str], train_idx: np.ndarray) -> List[Table]:
+    def fold_tables_cached(self, key, modalities: Sequence[str], train_idx: np.ndarray, with_covariates: bool = True) -> List[Table]:
         """fold_tables with the (fold key, modality) tables and the fold's covariates built once: the models of a fold
         share them (same HBM buffers: one copy in L2 / Infinity Cache for all of them, nm_job_t.shared_cov)."""
         ck = (key, "rows")
@@ -105,9 +105,11 @@ class DeviceCohort:
             rows = torch.as_tensor(np.asarray(train_idx, dtype=np.int32)).to(self.device)
             self._fold_cache[ck] = (rows, self.one_hot(rows))
         rows, c = self._fold_cache[ck]
+        if not with_covariates:
+            c = torch.zeros(int(rows.numel()), 0, dtype=torch.float32, device=self.device)
         out = []
         for m in modalities:
-            tk = (key, m)
+            tk = (key, m, with_covariates)
             if tk not in self._fold_cache:
                 center, scale = self.scaler_fit(m, rows)
                 self._fold_cache[tk] = self.table(m, rows, center, scale, c)

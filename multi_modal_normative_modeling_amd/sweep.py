@@ -27,6 +27,13 @@ METRIC_COLUMNS = ("job_id", "fold", "proc_id", "final_total_loss", "steps_per_s"
 N_METRICS = len(METRIC_COLUMNS)
 
 
+# -Model values of the train script (multimodal_kfold_train_cvae_supervised.py:149-157) -> (ModelSpec.kind, single-expert
+# bypass, combine forced to 'poe')
+MODEL_KINDS = {"cVAE_multimodal": ("multimodal", True, False), "mmJSD": ("multimodal", False, True),
+               "DMVAE": ("dmvae", False, True), "WeightedDMVAE": ("weighted_dmvae", False, True),
+               "mvtCAE": ("mvtcae", False, False), "mmVAEPlus": ("mmvaeplus", False, True)}
+
+
 @dataclass(frozen=True)
 class Cell:
     job_id: int
@@ -76,7 +83,7 @@ def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Ten
 def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int, epochs: int, device, out_dir=None,
               lr: float = 1e-4, steps_per_launch: int = 64, oversample_percentage: Optional[float] = None,
               hidden: Sequence[int] = workload.HIDDEN, latent: int = workload.LATENT,
-              per_procedure_dirs: bool = False) -> torch.Tensor:
+              per_procedure_dirs: bool = False, model: str = "cVAE_multimodal") -> torch.Tensor:
     """Train the given cells concurrently, run the ROI-wise deviation pass, return the metric rows.
     `oversample_percentage` switches the training rows to the train script's own recipe (utils.generate_kfold_ids:
     KFold over healthy + other, bootstrap resample with replacement, merged back in table order); None = the plain
@@ -90,6 +97,9 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         hc = cohort.dia == 1
         ids = prep.generate_kfold_ids(cohort.iid[hc], cohort.iid[~hc], oversample_percentage, n_folds)
         folds = [(prep.rows_of_ids(cohort.iid, tr), prep.rows_of_ids(cohort.iid, te)) for tr, te in ids]
+    if model not in MODEL_KINDS:
+        raise ValueError(f"Model '{model}' is not recognized. Available models are: {', '.join(MODEL_KINDS)}")   # :170-171
+    kind, bypass, force_poe = MODEL_KINDS[model]
     jobs: List[Job] = []
     # the fold's tables are built on the device from the raw cohort (scaler fit, covariate bins, early-fusion concat,
     # packing: prep_device.py), once per (fold, modality); the cells of a fold share them
@@ -97,10 +107,11 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
     dc = DeviceCohort(cohort, device)
     for c in cells:
         mods, combine = workload.procedure_modalities(c.procedure)
-        tables = dc.fold_tables_cached(c.fold, mods, folds[c.fold][0])
-        spec = ModelSpec([t.D for t in tables], list(hidden), int(latent), workload.C_DIM)
-        jobs.append(Job(spec, tables, combine=combine, lr=lr, seed=1000 * c.fold + c.job_id, init_seed=42 + c.job_id,
-                        loss_cap=max(8, epochs * 8)))
+        # (the DMVAE family's networks take no covariates: its tables are packed without the covariate block)
+        tables = dc.fold_tables_cached(c.fold, mods, folds[c.fold][0], with_covariates=kind not in ("dmvae", "weighted_dmvae", "mmvaeplus"))
+        spec = ModelSpec([t.D for t in tables], list(hidden), int(latent), workload.C_DIM, True, kind)
+        jobs.append(Job(spec, tables, combine="poe" if force_poe else combine, lr=lr, seed=1000 * c.fold + c.job_id,
+                        init_seed=42 + c.job_id, loss_cap=max(8, epochs * 8), single_bypass=bypass))
     # cells of different shapes take different time per step: group by shape so a launch is balanced
     groups: Dict[tuple, List[int]] = {}
     for i, j in enumerate(jobs):
@@ -157,18 +168,22 @@ def deviation_roiwise_many(views, cohort: prep.SyntheticCohort, device, want_mat
         return []
     from .layout import ParamLayout
     c = prep.one_hot_covariates(cohort.age, cohort.gender) if covariates is None else covariates
-    tables: Dict[str, Table] = {}
+    tables: Dict[tuple, Table] = {}
     ones = []
     for job, m, name in views:
-        if name not in tables:
+        with_c = job.spec.net_c_dim > 0
+        if (name, with_c) not in tables:
             src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
             center, scale = prep.robust_scaler_fit(src.astype(np.float32))
-            tables[name] = Table(prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32), c, device)
-        table = tables[name]
-        spec1 = ModelSpec([job.spec.input_dims[m]], list(job.spec.hidden), job.spec.latent, job.spec.c_dim)
+            xs_ = prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32)
+            tables[(name, with_c)] = Table(xs_, c if with_c else np.zeros((len(xs_), 0), dtype=np.float32), device)
+        table = tables[(name, with_c)]
+        spec1 = ModelSpec([job.spec.input_dims[m]], list(job.spec.hidden), job.spec.latent, job.spec.c_dim, job.spec.non_linear,
+                          job.spec.kind if job.spec.kind in ("mvtcae", "dmvae", "weighted_dmvae", "mmvaeplus") else "multimodal")
         sd = job.state_dict()
-        st = {k: sd[k.replace("_list.0.", f"_list.{m}.")] for k in ParamLayout(spec1).names}
-        one = Job(spec1, [table], combine="poe", state=st, seed=job.seed + 7919 * (m + 1), n_tiles_ws=table.n_tiles)
+        st = {k: (sd[k][m:m + 1] if k == "weights" else sd[k.replace("_list.0.", f"_list.{m}.")]) for k in ParamLayout(spec1).names}
+        one = Job(spec1, [table], combine="poe", state=st, seed=job.seed + 7919 * (m + 1), n_tiles_ws=table.n_tiles,
+                  single_bypass=job.single_bypass)
         one.enable_exports(loc=False, sqerr=want_matrix, rowdev=True, latent=False)
         ones.append(one)
     # one launch per distinct table height (all-subject tables of one cohort: a single launch)
@@ -423,8 +438,8 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     replaces run_cells in the CPU rehearsal tests (the real one needs a GPU)."""
     import os
     args = build_parser().parse_args(argv)
-    if args.model != "cVAE_multimodal":
-        raise ValueError("Model not found")                                   # multimodal_kfold_train_cvae_supervised.py:170-171
+    if args.model not in MODEL_KINDS:                                         # multimodal_kfold_train_cvae_supervised.py:170-171
+        raise ValueError(f"Model '{args.model}' is not recognized. Available models are: {', '.join(MODEL_KINDS)}")
     procedures = list(args.procedure)
     if args.single_modality:
         procedures = [f"SM-{args.single_modality}"]
@@ -458,7 +473,7 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     runner = _run_cells or run_cells
     oversample = None if args.oversample_percentage == 1.0 and args.training_class == "nm" else args.oversample_percentage
     # run_cells writes a cell's CSVs into <out>/<procedure>/ when procedures share modalities (per_procedure_dirs)
-    kw = {} if _run_cells is not None else {"per_procedure_dirs": True}
+    kw = {} if _run_cells is not None else {"per_procedure_dirs": True, "model": args.model}
     local = runner(cohort, mine, args.n_splits, args.epochs, device, out_dir=None if args.no_csv else out_dir,
                    lr=args.base_learning_rate, oversample_percentage=oversample, hidden=hidden, latent=latent, **kw)
     max_rows = (len(cells) + world - 1) // world

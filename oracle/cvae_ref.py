@@ -555,3 +555,159 @@ def loss_endtoend(spec: Spec, xes, fwd, labels, margin=1.0, weightcontrastive=0.
     total = weight_rec * (rh + rd) + weight_kl * kl + ce + weightcontrastive * contrastive
     return {"total_loss": total, "recon_loss_health": rh, "recon_loss_disease": rd, "kl_loss": kl,
             "classification_loss": ce, "contrastive_loss": contrastive}
+
+
+# ----------------------------------------------------------------------------------------
+# N4  DMVAE / WeightedDMVAE / mmVAEPlus (cVAE.py:1453-1747, 1895-2002)
+# ----------------------------------------------------------------------------------------
+@dataclass
+class DmSpec:
+    """Constructor arguments of the DMVAE family.  VariationalEncoder (cVAE.py:1453-1466): x -> relu(fc1) -> relu(fc2)
+    -> fc_mu / fc_logvar (no covariates); VariationalDecoder (:1468-1479): z -> relu(fc1) -> relu(fc2) -> sigmoid(fc_out).
+    s_dim = c_dim (:1506): the first s_dim columns of mu are the modality's private latent, the rest is shared."""
+    input_dims: Sequence[int]
+    hidden: Sequence[int]          # exactly two widths
+    latent: int
+    c_dim: int
+    cls: str = "DMVAE"             # DMVAE | WeightedDMVAE | mmVAEPlus
+
+    @property
+    def M(self) -> int:
+        return len(self.input_dims)
+
+    @property
+    def n_private(self) -> int:
+        return min(self.c_dim, self.latent)    # mu[:, :s_dim] of a [B, latent] tensor
+
+    @property
+    def beta(self) -> float:
+        return 0.05 if self.cls == "mmVAEPlus" else 1.0        # cVAE.py:1911 / :1507
+
+
+def dm_param_names(spec: DmSpec) -> List[str]:
+    """state_dict order: a module's own parameters (`weights`) come before its children's."""
+    names = ["weights"] if spec.cls == "WeightedDMVAE" else []
+    for m in range(spec.M):
+        for l in ("fc1", "fc2", "fc_mu", "fc_logvar"):
+            names += [f"encoder_list.{m}.{l}.weight", f"encoder_list.{m}.{l}.bias"]
+    for m in range(spec.M):
+        for l in ("fc1", "fc2", "fc_out"):
+            names += [f"decoder_list.{m}.{l}.weight", f"decoder_list.{m}.{l}.bias"]
+    return names
+
+
+def dm_forward(P, spec: DmSpec, xes, eps):
+    """forward_multimodal of the DMVAE family (cVAE.py:1536-1558): eps [B, >= Z - s] is the draw of the shared latent."""
+    S, Zc = spec.n_private, spec.latent - spec.n_private
+    mus, lvs = [], []
+    for m in range(spec.M):
+        p = f"encoder_list.{m}."
+        h = torch.relu(linear(xes[m], P[p + "fc1.weight"], P[p + "fc1.bias"]))
+        h = torch.relu(linear(h, P[p + "fc2.weight"], P[p + "fc2.bias"]))
+        mus.append(linear(h, P[p + "fc_mu.weight"], P[p + "fc_mu.bias"]))
+        lvs.append(linear(h, P[p + "fc_logvar.weight"], P[p + "fc_logvar.bias"]))
+    mu_c = torch.stack([m_[:, S:] for m_ in mus])
+    lv_c = torch.stack([l_[:, S:] for l_ in lvs])
+    var_inv = 1.0 / torch.exp(lv_c)                                           # ProductOfExperts2, cVAE.py:1481-1489
+    mu_j = torch.sum(mu_c * var_inv, dim=0) / torch.sum(var_inv, dim=0)
+    lv_j = torch.log(1.0 / torch.sum(var_inv, dim=0))
+    z = mu_j + eps[:, :Zc] * torch.exp(0.5 * lv_j)
+    recons = []
+    for m in range(spec.M):
+        p = f"decoder_list.{m}."
+        zc = torch.cat((z, mus[m][:, :S]), dim=1)
+        h = torch.relu(linear(zc, P[p + "fc1.weight"], P[p + "fc1.bias"]))
+        h = torch.relu(linear(h, P[p + "fc2.weight"], P[p + "fc2.bias"]))
+        recons.append(torch.sigmoid(linear(h, P[p + "fc_out.weight"], P[p + "fc_out.bias"])))
+    return {"x_recons": recons, "mu_c": mu_j, "logvar_c": lv_j}
+
+
+def dm_loss(P, spec: DmSpec, xes, fwd):
+    """loss_function_multimodal (cVAE.py:1563-1575, :1693-1710, :1967-1979): KL of the shared posterior once per modality,
+    ll_i = -0.5 sum (x_i - x_hat_i)^2 mean over rows; total = beta * kl - ll (weights[i] on both terms for WeightedDMVAE)."""
+    klb = -0.5 * torch.sum(1 + fwd["logvar_c"] - fwd["mu_c"].pow(2) - torch.exp(fwd["logvar_c"]), dim=1).mean(0)
+    kl, ll = 0, 0
+    for i in range(spec.M):
+        w = P["weights"][i] if spec.cls == "WeightedDMVAE" else 1.0
+        kl = kl + klb * w
+        ll = ll + (-0.5 * torch.sum((xes[i] - fwd["x_recons"][i]) ** 2, dim=1).mean(0)) * w
+    return {"total": kl * spec.beta - ll, "kl": kl, "ll": ll}
+
+
+def dm_train_step(P, opt: Adam, spec: DmSpec, xes, eps):
+    leaves = {n: P[n].detach().clone().requires_grad_(True) for n in opt.names}
+    fwd = dm_forward(leaves, spec, xes, eps)
+    loss = dm_loss(leaves, spec, xes, fwd)
+    gl = torch.autograd.grad(loss["total"], [leaves[n] for n in opt.names], allow_unused=True)
+    grads = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(opt.names, gl)}
+    opt.step(P, grads)
+    return {k: v.detach() for k, v in loss.items()}, grads, fwd
+
+
+# ----------------------------------------------------------------------------------------
+# N4  mvtCAE (cVAE.py:1754-1893)
+# ----------------------------------------------------------------------------------------
+MVT_BETA = 1e-4          # cVAE.py:1771
+MVT_LL_W = 1e-5          # cVAE.py:1877 (the log-likelihood enters the total with a PLUS sign)
+MVT_VAR_FLOOR = 1e-6     # cVAE.py:1823
+
+
+def mvt_combine(mus, variances, combine: str, alphas):
+    """mvtCAE.combine_latent (cVAE.py:1808-1825): no single-expert bypass; 'poe' hands the VARIANCES to ProductOfExperts2
+    as if they were log variances and takes the returned log variance as the joint variance (:1782-1783, 1481-1489); the
+    other combiners as in cVAE_multimodal; the joint variance is clamped at 1e-6."""
+    combine = combine.lower()
+    if combine == "poe":
+        var_inv = 1.0 / torch.exp(variances)
+        mu = torch.sum(mus * var_inv, dim=0) / torch.sum(var_inv, dim=0)
+        var = torch.log(1.0 / torch.sum(var_inv, dim=0))
+    else:
+        mu, var = combine_latent(mus, variances, combine, alphas, single_bypass=False)
+    return mu, torch.clamp(var, min=MVT_VAR_FLOOR)
+
+
+def mvt_total_correlation(mus, mu_joint, latent: int):
+    """mvtCAE.total_correlation (cVAE.py:1862-1869) as written: per latent column, logsumexp over the batch of the joint
+    mean minus its own (scalar) mean, minus the mean over experts of logsumexp over the batch of the expert means."""
+    tc = 0
+    for i in range(latent):
+        a = mu_joint[:, i].logsumexp(dim=0) - mu_joint[:, i].logsumexp(dim=0).mean()
+        b = torch.stack([mus[j][:, i].logsumexp(dim=0) for j in range(len(mus))]).mean(dim=0)
+        tc = tc + a - b
+    return tc
+
+
+def mvt_forward(P, spec: Spec, xes, cs, combine: str, eps):
+    enc = [encoder_fwd(P, spec, m, xes[m], cs[m]) for m in range(spec.M)]
+    mus = torch.stack([e[0] for e in enc])
+    variances = torch.exp(torch.stack([e[1] for e in enc]))
+    alphas = [P[f"alpha_m_list.{m}"] for m in range(spec.M)]
+    mu, var = mvt_combine(mus, variances, combine, alphas)
+    logvar = torch.log(var)
+    z = reparameterise(mu, logvar, eps)
+    dec = [decoder_fwd(P, spec, m, z, cs[m]) for m in range(spec.M)]
+    return {"locs": [d[0] for d in dec], "scales": [d[1] for d in dec], "mu": mu, "logvar": logvar, "z": z, "mus": mus}
+
+
+def mvt_loss(spec: Spec, xes, fwd):
+    """cVAE.py:1871-1882: sum over the modalities of kl + 1e-5 * ll_i + beta * tc."""
+    out = {"total": 0, "kl": 0, "ll": 0, "tc": 0}
+    for i in range(spec.M):
+        kl = calc_kl(fwd["mu"], fwd["logvar"])
+        ll = compute_ll(xes[i], fwd["locs"][i], fwd["scales"][i])
+        tc = mvt_total_correlation(fwd["mus"], fwd["mu"], spec.latent)
+        out["total"] = out["total"] + kl + MVT_LL_W * ll + MVT_BETA * tc
+        out["kl"] = out["kl"] + kl
+        out["ll"] = out["ll"] + ll
+        out["tc"] = out["tc"] + tc
+    return out
+
+
+def mvt_train_step(P, opt: Adam, spec: Spec, xes, cs, combine: str, eps):
+    leaves = {n: P[n].detach().clone().requires_grad_(True) for n in opt.names}
+    fwd = mvt_forward(leaves, spec, xes, cs, combine, eps)
+    loss = mvt_loss(spec, xes, fwd)
+    gl = torch.autograd.grad(loss["total"].sum(), [leaves[n] for n in opt.names], allow_unused=True)
+    grads = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(opt.names, gl)}
+    opt.step(P, grads)
+    return {k: v.detach() for k, v in loss.items()}, grads, fwd

@@ -122,6 +122,88 @@ def case_multimodal(ref, name, dims, c_dim, hidden, Z, B, combine, n_steps, seed
     print("wrote", name, {k: float(out[k][0]) for k in out if k.startswith("loss")})
 
 
+def case_dm(ref, name, cls, dims, c_dim, hidden, Z, B, n_steps, seed, store_steps=(1,)):
+    """DMVAE / WeightedDMVAE / mmVAEPlus (cVAE.py:1491-1747, 1895-2002): covariate-free ReLU encoders / sigmoid decoders,
+    the first min(c_dim, Z) latent columns private, the rest fused by ProductOfExperts2 and sampled; inputs in [0, 1]."""
+    import contextlib, io
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    M = len(dims)
+    model = getattr(ref, cls)(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim,
+                              learning_rate=1e-4, modalities=M, non_linear=True)
+    S = min(c_dim, Z)
+    Zc = Z - S
+    out = {"meta": np.array([M, c_dim, Z, B, n_steps]), "dims": np.array(dims), "hidden": np.array(hidden),
+           "combine": np.array("poe"), "cls": np.array(cls)}
+    out.update(sd_np(model, "w0:"))
+    xs = [torch.rand(n_steps, B, d, generator=g) for d in dims]
+    eps = torch.randn(n_steps, B, Z, generator=g)          # the first Zc columns are the draw of the shared latent
+    for m in range(M):
+        out[f"x{m}"] = xs[m].numpy()
+    out["eps"] = eps.numpy()
+    out["c"] = np.zeros((n_steps, B, 0), dtype=np.float32)
+    for s in range(n_steps):
+        xes = [xs[m][s] for m in range(M)]
+        with fixed_eps([eps[s][:, :Zc]]):
+            fwd = model.forward_multimodal(xes, None, "poe")
+        with contextlib.redirect_stdout(io.StringIO()):     # WeightedDMVAE prints per step (cVAE.py:1702)
+            loss = model.loss_function_multimodal(xes, fwd)
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        if s == 0:
+            out["mu"] = fwd["mu_c"].detach().numpy().copy()
+            out["logvar"] = fwd["logvar_c"].detach().numpy().copy()
+            for m in range(M):
+                out[f"loc{m}"] = fwd["x_recons"][m].detach().numpy().copy()
+            out.update(grads_np(model, "g0:"))
+        out[f"loss{s}"] = np.array([float(loss["total"]), float(loss["kl"]), float(loss["ll"])], dtype=np.float64)
+        model.optimizer1.step()
+        if (s + 1) in store_steps:
+            out.update(sd_np(model, f"w{s + 1}:"))
+            out.update(adam_np(model.optimizer1, model, f"a{s + 1}:"))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name, {k: [float(v) for v in out[k]] for k in out if k.startswith("loss")}, list(sd_np(model, "").keys())[:3])
+
+
+def case_mvt(ref, name, dims, c_dim, hidden, Z, B, combine, n_steps, seed, store_steps=(1,)):
+    """mvtCAE (cVAE.py:1754-1893): case_multimodal with the tc term logged as a fourth loss entry."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    M = len(dims)
+    model = ref.mvtCAE(input_dim_list=list(dims), hidden_dim=list(hidden), latent_dim=Z, c_dim=c_dim, learning_rate=1e-4,
+                       modalities=M, non_linear=True)
+    out = {"meta": np.array([M, c_dim, Z, B, n_steps]), "dims": np.array(dims), "hidden": np.array(hidden),
+           "combine": np.array(combine)}
+    out.update(sd_np(model, "w0:"))
+    xs = [torch.randn(n_steps, B, d, generator=g) * 1.3 + 0.1 for d in dims]
+    c = torch.stack([onehot_cov(g, B, c_dim) for _ in range(n_steps)])
+    eps = torch.randn(n_steps, B, Z, generator=g)
+    for m in range(M):
+        out[f"x{m}"] = xs[m].numpy()
+    out["c"], out["eps"] = c.numpy(), eps.numpy()
+    for s in range(n_steps):
+        xes = [xs[m][s] for m in range(M)]
+        cs = [c[s].long() for _ in range(M)]
+        with fixed_eps([eps[s]]):
+            fwd = model.forward_multimodal(xes, cs, combine)
+        loss = model.loss_function_multimodal(xes, fwd)
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        if s == 0:
+            out["mu"] = fwd["mu_multimodal"].detach().numpy().copy()
+            out["logvar"] = fwd["logvar_multimodal"].detach().numpy().copy()
+            for m in range(M):
+                out[f"loc{m}"] = fwd["x_recons"][m].loc.detach().numpy().copy()
+            out.update(grads_np(model, "g0:"))
+        out[f"loss{s}"] = np.array([float(loss["total"]), float(loss["kl"]), float(loss["ll"]), float(loss["tc"])], dtype=np.float64)
+        model.optimizer1.step()
+        if (s + 1) in store_steps:
+            out.update(sd_np(model, f"w{s + 1}:"))
+            out.update(adam_np(model.optimizer1, model, f"a{s + 1}:"))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name, {k: [float(v) for v in out[k]] for k in out if k.startswith("loss")})
+
+
 def case_single(ref, name, D, c_dim, hidden, Z, B, seed):
     """class cVAE (cVAE.py:391-562): forward + loss_function + pred_recon/pred_latent."""
     import pandas as pd
@@ -318,7 +400,7 @@ def main():
         import builtins
         keep = lambda fn: (lambda r, name, *a, **k: fn(r, name, *a, **k) if name in only else None)
         g = globals()
-        for fname in ("case_multimodal", "case_single", "case_deviation", "case_regression", "case_endtoend"):
+        for fname in ("case_multimodal", "case_single", "case_deviation", "case_regression", "case_endtoend", "case_dm", "case_mvt"):
             g[fname] = keep(g[fname])
         orig_csv = g["case_csv_headers"]
         g["case_csv_headers"] = lambda name: orig_csv(name) if name in only else None
@@ -341,6 +423,15 @@ def main():
     # baseline zoo: mmJSD (cVAE.py:1354-1448) = product of experts without the single-expert
     # bypass; its JSD term compares the joint posterior with itself and is identically zero
     case_multimodal(ref, "mmjsd3", (23, 17, 29), 7, (24, 16), 6, 19, "gpoe", 3, seed=109, store_steps=(3,), cls="mmJSD")
+    # DMVAE family: (a) the configuration the scripts run (c_dim = 29 >= latent: every latent column is private, the
+    # models are deterministic autoencoders), (b) c_dim < latent: 3 private + 7 shared columns
+    case_dm(ref, "dmvae3", "DMVAE", (23, 17, 29), 29, (24, 16), 10, 19, 3, seed=110, store_steps=(3,))
+    case_dm(ref, "dmvae3_shared", "DMVAE", (23, 17, 29), 3, (24, 16), 10, 32, 3, seed=111, store_steps=(3,))
+    case_dm(ref, "wdmvae3_shared", "WeightedDMVAE", (23, 17, 29), 3, (24, 16), 10, 32, 3, seed=112, store_steps=(3,))
+    case_dm(ref, "mmvaeplus3_shared", "mmVAEPlus", (23, 17, 29), 4, (24, 16), 12, 19, 3, seed=113, store_steps=(3,))
+    # mvtCAE: its 'poe' (ProductOfExperts2 on variances) and a standard combiner, both with the variance clamp and the tc term
+    for comb in ("poe", "gpoe", "mopoe"):
+        case_mvt(ref, f"mvtcae3_{comb}", (23, 17, 29), 7, (24, 16), 6, 19, comb, 3, seed=114, store_steps=(3,))
 
 
 if __name__ == "__main__":

@@ -169,6 +169,17 @@ def test_sweep_cli_entry_one_gpu():
                     assert list(df.columns) == ["IID"] + [f"ROI_{i}" for i in range(379)] and len(df) == 320
 
 
+@pytest.mark.parametrize("model", ["DMVAE", "WeightedDMVAE", "mvtCAE", "mmJSD"])
+def test_sweep_cli_zoo_models(model):
+    """-Model of the train script (multimodal_kfold_train_cvae_supervised.py:149-171) through the sweep entry point: two
+    SE cells of a baseline-zoo model train, run the deviation pass and come back with finite metrics."""
+    with tempfile.TemporaryDirectory() as d:
+        table = sweep.main(["-P", "SE-PoE", "-E", "2", "-K", "2", "-Model", model, "--subjects", "300", "--out-dir", d, "--no-csv"])
+    assert table.shape == (2, sweep.N_METRICS) and torch.isfinite(table).all()
+    with pytest.raises(ValueError):
+        sweep.main(["-Model", "nope", "--subjects", "32"])
+
+
 def test_sweep_end_to_end_small():
     """Two cells, a few epochs on a 320-subject synthetic cohort: training lowers the loss, the
     deviation CSVs have the reference layout and bit-exact IID / ROI indexing."""
@@ -611,6 +622,151 @@ def test_mmjsd_matches_reference():
     sd, w0 = model.state_dict(), g.weights("w0")
     for m in range(g.M):
         assert torch.equal(sd[f"alpha_m_list.{m}"], w0[f"alpha_m_list.{m}"])          # no gradient reaches alpha
+
+
+@pytest.mark.parametrize("name,cls", [("dmvae3", "DMVAE"), ("dmvae3_shared", "DMVAE"), ("wdmvae3_shared", "WeightedDMVAE"),
+                                      ("mmvaeplus3_shared", "mmVAEPlus")])
+def test_dm_family_matches_reference(name, cls):
+    """DMVAE / WeightedDMVAE / mmVAEPlus of the baseline zoo (cVAE.py:1491-1747, 1895-2002) on the step kernel, through the
+    reference-named classes: losses of every step against the reference's own numbers (ll and total within 1e-4), the
+    shared posterior and reconstructions of step 0, every gradient of step 0 against the oracle with bf16 GEMM operands
+    (the arithmetic the kernel is specified to do) and against the reference (direction / size), and the 3-step Adam
+    trajectory.  dmvae3 is the shape the scripts run (c_dim 29 >= latent 10: every latent column private, KL = 0)."""
+    g = Golden(name)
+    model = getattr(nm, cls)(g.dims, g.hidden, g.Z, g.c_dim, learning_rate=1e-4, modalities=g.M, non_linear=True)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    spec = R.DmSpec(g.dims, g.hidden, g.Z, g.c_dim, cls)
+    # step-0 gradients of the oracle in bf16-operand mode
+    P0 = g.weights("w0")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        l16 = R.dm_loss(leaves, spec, g.xs(0), R.dm_forward(leaves, spec, g.xs(0), g.t("eps")[0]))
+        l16["total"].backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    for s in range(g.n_steps):
+        xes = [x.to(DEV) for x in g.xs(s)]
+        model._eps_override = g.t("eps")[s]
+        fwd = model.forward_multimodal(xes, None, "poe")
+        loss = model.loss_function_multimodal(xes, fwd)
+        ref = g.z[f"loss{s}"]
+        assert abs(float(loss["ll"]) - ref[2]) <= 1e-4 * abs(ref[2]), (s, float(loss["ll"]), ref[2])
+        assert abs(float(loss["total"]) - ref[0]) <= 1e-4 * abs(ref[0]), (s, float(loss["total"]), ref[0])
+        assert abs(float(loss["kl"]) - ref[1]) <= 5e-3 * abs(ref[1]) + 1e-6, (s, float(loss["kl"]), ref[1])
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        if s == 0:
+            if g.t("mu").numel():
+                assert rel_err(fwd["mu_c"].cpu(), g.t("mu")) < 2e-2 and rel_err(fwd["logvar_c"].cpu(), g.t("logvar")) < 2e-2
+            for m in range(g.M):
+                assert float((fwd["x_recons"][m].cpu() - g.t(f"loc{m}")).abs().max()) < 5e-3          # sigmoid outputs in (0, 1)
+            got = {n: p.grad.cpu() for n, p in model._named_views()}
+            for k, gref in g.grads("g0").items():
+                a, r32, r16 = got[k].flatten().float(), gref.flatten(), leaves[k].grad.flatten()
+                if float(r32.norm()) < 1e-12:                      # (fc_logvar of an all-private latent: no gradient at all)
+                    assert float(a.norm()) < 1e-9, k
+                    continue
+                assert float((a - r16).norm()) <= 3e-2 * float(r16.norm()) + 1e-9, (k, "bf16 oracle")
+                # vs the reference's fp32 numbers: direction and size.  ReLU (slope 0) makes a pre-activation that bf16
+                # rounding moves across zero switch a whole unit off, so the spread is wider than with LeakyReLU(0.01);
+                # the fp32 <-> bf16-operand oracle distance is the scale
+                noise = float((r16 - r32).norm())
+                assert float((a - r32).norm()) <= max(0.15 * float(r32.norm()), 1.5 * noise) + 1e-9, (k, "fp32 reference")
+                if a.numel() >= 8:
+                    cos16 = float(torch.nn.functional.cosine_similarity(r16, r32, dim=0))
+                    assert float(torch.nn.functional.cosine_similarity(a, r32, dim=0)) > min(0.99, cos16 - 5e-3), k
+        model.optimizer1.step()
+    ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    assert ok, worst
+    preds = model.pred_recon([pd.DataFrame(x.numpy()) for x in g.xs(0)], None, DEV, "poe")
+    devs = model.reconstruction_deviation_multimodal([x.numpy() for x in g.xs(0)], preds)
+    assert [p.shape for p in preds] == [(g.B, d) for d in g.dims] and devs[0].shape == (g.B,)
+
+
+@pytest.mark.parametrize("name", ["mvtcae3_poe", "mvtcae3_gpoe", "mvtcae3_mopoe"])
+def test_mvtcae_matches_reference(name):
+    """mvtCAE of the baseline zoo (cVAE.py:1754-1893) through its reference-named class: the four loss terms of every
+    step against the reference's own numbers (total, kl, ll, tc), the joint posterior, every gradient of step 0 against
+    the oracle with bf16 GEMM operands and against the reference, and the 3-step Adam trajectory.  `poe` is the
+    ProductOfExperts2-on-variances quirk (the clamp at 1e-6 is active there: KL ~ 80)."""
+    g = Golden(name)
+    model = nm.mvtCAE(g.dims, g.hidden, g.Z, g.c_dim, learning_rate=1e-4, modalities=g.M, non_linear=True)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    spec = R.Spec(g.dims, g.hidden, g.Z, g.c_dim)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in g.weights("w0").items()}
+    c0 = g.t("c")[0].long()
+    R.set_operand_rounding("bf16")
+    try:
+        fwd16 = R.mvt_forward(leaves, spec, g.xs(0), [c0] * g.M, g.combine, g.t("eps")[0])
+        R.mvt_loss(spec, g.xs(0), fwd16)["total"].sum().backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    for s in range(g.n_steps):
+        xes = [x.to(DEV) for x in g.xs(s)]
+        c = g.t("c")[s].long().to(DEV)
+        model._eps_override = g.t("eps")[s]
+        fwd = model.forward_multimodal(xes, [c] * g.M, g.combine)
+        loss = model.loss_function_multimodal(xes, fwd)
+        ref = g.z[f"loss{s}"]
+        assert abs(float(loss["ll"]) - ref[2]) <= 1e-4 * abs(ref[2]), (s, float(loss["ll"]), ref[2])
+        assert abs(float(loss["tc"]) - ref[3]) <= 2e-3 * abs(ref[3]), (s, float(loss["tc"]), ref[3])
+        assert abs(float(loss["kl"]) - ref[1]) <= 5e-3 * abs(ref[1]) + 1e-4, (s, float(loss["kl"]), ref[1])
+        assert abs(float(loss["total"]) - ref[0]) <= 5e-3 * abs(ref[0]) + 2e-3, (s, float(loss["total"]), ref[0])
+        model.optimizer1.zero_grad()
+        loss["total"].backward()
+        if s == 0:
+            assert rel_err(fwd["mu_multimodal"].cpu(), g.t("mu")) < 2e-2
+            # the joint log variance is log(max(u, 1e-6)) with u = -log(sum of exp(-var_m)) for 'poe': ill-conditioned
+            # where u crosses zero, so the fp32 <-> bf16-operand oracle distance is the scale
+            lv16 = fwd16["logvar"].detach()
+            noise = float((lv16 - g.t("logvar")).abs().max())
+            assert float((fwd["logvar_multimodal"].cpu() - lv16).abs().max()) <= 1.5 * noise + 2e-2
+            got = {n: p.grad.cpu() for n, p in model._named_views()}
+            for k, gref in g.grads("g0").items():
+                a, r32, r16 = got[k].flatten().float(), gref.flatten(), leaves[k].grad.flatten()
+                if float(r32.norm()) < 1e-12:
+                    assert float(a.norm()) < 1e-9, k
+                    continue
+                noise = float((r16 - r32).norm())
+                assert float((a - r16).norm()) <= 3e-2 * float(r16.norm()) + 1e-9, (k, "bf16 oracle")
+                assert float((a - r32).norm()) <= max(0.15 * float(r32.norm()), 1.5 * noise) + 1e-9, (k, "fp32 reference")
+        model.optimizer1.step()
+    ok, worst = _traj_ok(model.state_dict(), g.weights(f"w{g.n_steps}"), 1e-4, g.n_steps)
+    assert ok, worst
+
+
+def test_dm_family_fused_training_and_split_launch():
+    """The DMVAE family inside the persistent kernel: 4 fused Adam steps of a WeightedDMVAE against the oracle's
+    trajectory (bf16-operand mode), and the split launch (one workgroup per modality) bit-identical to the single one."""
+    g = Golden("wdmvae3_shared")
+    spec = nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim, True, "weighted_dmvae")
+    xes, eps = g.xs(0), g.t("eps")[0]
+    out = []
+    for split in (False, True):
+        tabs = [nm.Table(x, torch.zeros(g.B, 0), DEV) for x in xes]
+        job = nm.Job(spec, tabs, combine="poe", state=g.weights("w0"))
+        job.set_eps(eps)
+        nm.JobSet([job]).train(4, split=split)
+        torch.cuda.synchronize()
+        out.append((job.params.cpu().clone(), job.adam_v.cpu().clone(), job.loss_log.cpu().clone(), job.state_dict()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    ospec = R.DmSpec(g.dims, g.hidden, g.Z, g.c_dim, "WeightedDMVAE")
+    P = {k: v.clone() for k, v in g.weights("w0").items()}
+    opt = R.Adam(P, R.dm_param_names(ospec))
+    R.set_operand_rounding("bf16")
+    try:
+        for _ in range(4):
+            R.dm_train_step(P, opt, ospec, xes, eps)
+    finally:
+        R.set_operand_rounding("fp32")
+    got = out[0][3]
+    moved = max(float((got[k] - g.weights("w0")[k]).abs().max()) for k in got)
+    worst = max(float((got[k] - P[k]).abs().max()) for k in got)
+    assert worst <= 0.3 * moved + 1e-7, (worst, moved)
+    assert float((got["weights"] - g.weights("w0")["weights"]).abs().max()) > 0         # the loss weights are learned
 
 
 def test_test_script_fold_outputs():

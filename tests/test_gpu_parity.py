@@ -321,3 +321,36 @@ def test_split_launch_many_small_models_and_refusal():
     st = torch.cuda.current_stream().cuda_stream
     assert lib.nm_launch_split(ptr, 96, 3, 0, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS, st) == -16
     assert big.split_parts() == 1
+
+
+def test_per_step_learning_rate_table_matches_oracle():
+    """The cyclic schedule of multimodal_kfold_cvae_nmmlp.py:376-381 as nm_job_t.lr_table: 6 fused Adam steps with a
+    different learning rate each, against the oracle stepping with the same rates (bf16-operand mode), and against a
+    constant-rate run (must differ)."""
+    from multi_modal_normative_modeling_amd import prep as P_
+    g = Golden("mm3_gpoe")
+    lrs = P_.cyclic_lr(6, 512, 256, 1e-5, 4e-4, 0.9)
+    assert len(set(lrs.tolist())) >= 4          # triangular: rises for 4 steps, then retraces
+    job = make_job(g, 0)
+    job.set_lr_table(lrs)
+    js = nm.JobSet([job])
+    const = make_job(g, 0)
+    cj = nm.JobSet([const])
+    rs = R.Spec(g.dims, g.hidden, g.Z, g.c_dim)
+    Pw = {k: v.clone() for k, v in g.weights("w0").items()}
+    opt = R.Adam(Pw, R.param_names(rs))
+    xes, c, eps = g.xs(0), g.t("c")[0], g.t("eps")[0]
+    R.set_operand_rounding("bf16")
+    try:
+        for i in range(6):
+            opt.lr = float(lrs[i])
+            R.train_step(Pw, opt, rs, xes, [c.long()] * g.M, g.combine, eps)
+    finally:
+        R.set_operand_rounding("fp32")
+    js.train(6); cj.train(6)
+    torch.cuda.synchronize()
+    got, cst = job.state_dict(), const.state_dict()
+    moved = max(float((got[k] - g.weights("w0")[k]).abs().max()) for k in got)
+    worst = max(float((got[k] - Pw[k]).abs().max()) for k in got)
+    assert worst <= 0.05 * moved + 1e-7, (worst, moved)         # same trajectory as the oracle under the same schedule
+    assert max(float((got[k] - cst[k]).abs().max()) for k in got) > 0.2 * moved      # and not the constant-rate one

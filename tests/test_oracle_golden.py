@@ -149,3 +149,51 @@ def test_committed_csv_known_answers():
     ficols = list(z["adni_fi_cols"])
     assert ficols[4:] == [str(i) for i in range(1, len(cols) - 4 + 1)]
     assert list(z["adni_err_cols"]) == ["participant_id", "DIA", "AGE", "PTGENDER", "Reconstruction error"]
+
+
+@pytest.mark.parametrize("name", ["dmvae3", "dmvae3_shared", "wdmvae3_shared", "mmvaeplus3_shared"])
+def test_dm_family_oracle_matches_reference(name):
+    """DMVAE / WeightedDMVAE / mmVAEPlus restated (oracle.dm_*) against the reference classes' own numbers: forward,
+    losses, every gradient, and the 3-step Adam trajectory (cVAE.py:1491-1747, 1895-2002)."""
+    g = Golden(name)
+    spec = R.DmSpec(g.dims, g.hidden, g.Z, g.c_dim, str(g.z["cls"]))
+    P = g.weights("w0")
+    assert list(P.keys()) == R.dm_param_names(spec)
+    opt = R.Adam(P, R.dm_param_names(spec))
+    for s in range(g.n_steps):
+        loss, grads, fwd = R.dm_train_step(P, opt, spec, g.xs(s), g.t("eps")[s])
+        ref = g.t(f"loss{s}")
+        for i, k in enumerate(("total", "kl", "ll")):
+            assert abs(float(loss[k]) - float(ref[i])) <= 2e-6 * abs(float(ref[i])) + 1e-7, (s, k)
+        if s == 0:
+            if g.t("mu").numel():                       # (c_dim >= latent: no shared latent at all)
+                assert float((fwd["mu_c"].detach() - g.t("mu")).abs().max()) <= 1e-6
+            for m in range(g.M):
+                assert float((fwd["x_recons"][m].detach() - g.t(f"loc{m}")).abs().max()) <= 1e-6
+            for k, gr in g.grads("g0").items():
+                assert float((grads[k] - gr).abs().max()) <= 2e-5 * float(gr.abs().max()) + 1e-9, k
+    for k, w in g.weights(f"w{g.n_steps}").items():
+        assert float((P[k] - w).abs().max()) <= 2e-6, k
+
+
+@pytest.mark.parametrize("name", ["mvtcae3_poe", "mvtcae3_gpoe", "mvtcae3_mopoe"])
+def test_mvtcae_oracle_matches_reference(name):
+    """mvtCAE restated (oracle.mvt_*) against the reference class: the variance-as-logvar product of experts, the clamp,
+    the total-correlation term, losses, gradients and the 3-step trajectory (cVAE.py:1754-1893)."""
+    g = Golden(name)
+    spec = R.Spec(g.dims, g.hidden, g.Z, g.c_dim)
+    P = g.weights("w0")
+    opt = R.Adam(P, R.param_names(spec))
+    for s in range(g.n_steps):
+        c = g.t("c")[s].long()
+        loss, grads, fwd = R.mvt_train_step(P, opt, spec, g.xs(s), [c] * g.M, g.combine, g.t("eps")[s])
+        ref = g.t(f"loss{s}")
+        for i, k in enumerate(("total", "kl", "ll", "tc")):
+            assert abs(float(loss[k]) - float(ref[i])) <= 5e-6 * abs(float(ref[i])) + 1e-7, (s, k, float(loss[k]), float(ref[i]))
+        if s == 0:
+            assert float((fwd["mu"].detach() - g.t("mu")).abs().max()) <= 1e-6
+            assert float((fwd["logvar"].detach() - g.t("logvar")).abs().max()) <= 1e-5
+            for k, gr in g.grads("g0").items():
+                assert float((grads[k] - gr).abs().max()) <= 2e-5 * float(gr.abs().max()) + 1e-9, k
+    for k, w in g.weights(f"w{g.n_steps}").items():
+        assert float((P[k] - w).abs().max()) <= 2e-6, k

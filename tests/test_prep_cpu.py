@@ -83,3 +83,17 @@ def test_generate_kfold_ids_matches_reference_recipe():
     merged = pd.merge(table, ids_df, on="IID")
     rows = prep.rows_of_ids(table["IID"].to_numpy(), got[0][0])
     assert np.array_equal(merged["v"].to_numpy(), table["v"].to_numpy()[rows])
+
+
+def test_cyclic_lr_schedule():
+    """prep.cyclic_lr against a direct transcription of the loop body's arithmetic at a few global steps and its
+    structural properties (starts near base, peaks at max * gamma after one step_size, decays per cycle)."""
+    lr = prep.cyclic_lr(400, 1024, 256, 1e-6, 5e-5, 0.98)
+    ss = 2 * np.ceil(1024 / 256)                      # 8 steps up, 8 down
+    assert lr.dtype == np.float64 and len(lr) == 400
+    assert abs(lr[int(ss) - 1] - (1e-6 + (5e-5 - 1e-6) * 0.98)) < 1e-18          # gs = step_size: x = 0, cycle = 1
+    assert abs(lr[int(2 * ss) - 1] - 1e-6) < 1e-18                                # gs = 2 step_size: x = 1 -> base
+    assert lr[int(3 * ss) - 1] < lr[int(ss) - 1] and lr[int(3 * ss) - 1] > lr[int(5 * ss) - 1]      # peaks decay by gamma
+    gs = 13
+    cycle = np.floor(1 + gs / (2 * ss)); x = np.abs(gs / ss - 2 * cycle + 1)
+    assert lr[gs - 1] == 1e-6 + (5e-5 - 1e-6) * max(0, 1 - x) * 0.98 ** cycle
