@@ -159,10 +159,19 @@ typedef struct nm_job {
   float*  out_z;          /* NM_F_EXPORT: [rows_alloc][Z] sampled z     (may be NULL)    */
   const float* dz_extra;  /* optional d L_extra / d z, [rows_alloc][Z] (classifier head, cVAE.py:2117) */
   /* regressor of cVAE_multimodal_regression (cVAE.py:2249-2253): Linear(sum D, 128) - ReLU -
-   * Linear(128, 64) - ReLU - Linear(64, 1) on cat_m(x_m - x_hat_m); used by nm_head_regression only */
+   * Linear(128, 64) - ReLU - Linear(64, 1) on cat_m(x_m - x_hat_m); used by nm_head_regression / nm_train_steps_head.
+   * regressor.0.weight is stored [128][Kh] with every modality's columns padded to whole 64-column chunks: modality m
+   * occupies columns [64 q_m, 64 q_m + D_m), q_m = sum_{j<m} ceil(D_j / 64), Kh = 64 sum_m ceil(D_m / 64); the pad
+   * columns are zero and stay zero (their residual operand is zero).  ParamLayout maps to and from the reference's
+   * [128][sum D] tensor. */
   int32_t reg_head;       /* 1: reg_w / reg_b are valid                                  */
   float   reg_lambda;     /* d total / d MSE  (lambda_reg, cVAE.py:2330-2346)            */
   int64_t reg_w[3], reg_b[3];   /* regressor.{0,2,4}.weight / .bias offsets in params   */
+  int64_t reg_s;          /* byte offset in wsh of regressor.0's shadow: Kh / 64 chunk images [128][72] + bias (nm_fill_shadow) */
+  uint16_t* reg_resid;    /* bf16 residual x - x_hat as chunk images [rows_alloc / 256][Kh / 64][256][72] (the layout of xb):
+                             written by an NM_F_EXPORT pass of the trunk, read by the head                         */
+  uint16_t* reg_dres;     /* [Kh / 64][256][72] (one 256-row tile: the batch in flight): d (lambda MSE) / d x_hat, written by
+                             the head's backward, added to the NLL gradient by the trunk's second pass (nm_train_steps_head) */
   const float* fi_target; /* [rows_alloc] regression target (may be NULL for forward)   */
   float*  out_fi_pred;    /* [rows_alloc] prediction                                     */
   /* Classifier of cVAE_multimodal_endtoend (cVAE.py:2004-2018): cls_layers blocks of Linear - BatchNorm1d -
@@ -234,14 +243,13 @@ int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps,
 int nm_grads(const nm_job_t* jobs_dev, int n_jobs, int step, void* stream);
 int nm_forward(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, void* stream);
 
-/* Regression head of cVAE_multimodal_regression (cVAE.py:2309-2346) on the exported reconstructions:
+/* Regression head of cVAE_multimodal_regression (cVAE.py:2309-2346) on the exported residuals:
  * one workgroup per (job, 256-row tile), tiles tile0 .. tile0 + n_tiles - 1 (training: the step's batch
  * b = step mod ceil(n_rows/256), n_tiles = 1; inference: all tiles).  `step` selects the loss_log row and the
- * Adam bias correction exactly as in nm_launch.  Reads mod[m].x_f32 and mod[m].out_loc (filled by a preceding
- * NM_F_EXPORT launch), writes out_fi_pred and loss_log[.][NM_LOSS_REG] (row `step` mod loss_cap).  With
- * NM_F_BACKWARD (needs fi_target) it also writes d(lambda * MSE)/d x_hat into mod[m].dloc_extra -- the
- * next nm_launch(NM_F_BACKWARD) adds it to the ELBO gradient -- and the regressor's own gradients
- * (NM_F_GRADS -> job.grads) or Adam update (NM_F_ADAM). */
+ * Adam bias correction exactly as in nm_launch.  Reads job.reg_resid (filled by a preceding NM_F_EXPORT launch),
+ * writes out_fi_pred and loss_log[.][NM_LOSS_REG] (row `step` mod loss_cap).  With NM_F_BACKWARD (needs fi_target)
+ * it also writes d(lambda * MSE)/d x_hat into job.reg_dres and the regressor's own gradients (NM_F_GRADS ->
+ * job.grads) or Adam update (NM_F_ADAM).  Training runs through nm_train_steps_head, which also consumes reg_dres. */
 int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags,
                        void* stream);
 
@@ -253,6 +261,17 @@ int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0
  * nm_head_regression; train-mode BatchNorm statistics are per tile (= per batch). */
 int nm_head_classifier(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags,
                        void* stream);
+
+/* n_steps train steps of head models in ONE persistent launch (one workgroup per job, no host round trip between
+ * steps, the trunk's forward evaluated once per step): per step the trunk forward with exports, the head (regression
+ * head: cVAE.py:2309-2346; classifier of the end-to-end model: cVAE.py:2106-2200) forward / loss / backward / Adam, then
+ * the trunk's backward + Adam with the head's extra gradients.  Replaces the per-step loops of
+ * multimodal_kfold_train_cvae_supervised_regression.py:112-125 and multimodal_kfold_cvae_nmpmcont.py:257-303.
+ * Every job needs its head's buffers set (reg_head + out_loc + dloc_extra + fi_target, or classifier + labels + out_z +
+ * out_rowdev + dz_extra + rowcoef_out); results equal the nm_launch(EXPORT) / nm_head_* / nm_launch(BACKWARD|ADAM)
+ * sequence.  flags: NM_F_TRACE / NM_F_PROFILE; NM_F_GRADS (n_steps == 1): no update, the gradients of the step's total
+ * go to job.grads instead (the eager facade's backward); NM_F_BNSTATS: the classifier's BatchNorm running statistics move. */
+int nm_train_steps_head(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, int flags, void* stream);
 
 /* ---- post-hoc metrics of the sweep on the device ------------------------------------
  * Sets are segments [offsets[s], offsets[s+1]) of the concatenated arrays; one workgroup per set, at most

@@ -73,6 +73,7 @@ class NmJob(C.Structure):
         ("loss_log", C.c_void_p), ("wsh", C.c_void_p), ("workspace", C.c_void_p), ("workspace_stride", C.c_int64),
         ("out_mu", C.c_void_p), ("out_logvar", C.c_void_p), ("out_z", C.c_void_p), ("dz_extra", C.c_void_p),
         ("reg_head", C.c_int32), ("reg_lambda", C.c_float), ("reg_w", C.c_int64 * 3), ("reg_b", C.c_int64 * 3),
+        ("reg_s", C.c_int64), ("reg_resid", C.c_void_p), ("reg_dres", C.c_void_p),
         ("fi_target", C.c_void_p), ("out_fi_pred", C.c_void_p),
         ("cls_layers", C.c_int32), ("cls_classes", C.c_int32), ("cls_width", C.c_int32 * NM_MAX_CLS),
         ("cls_train", C.c_int32), ("cls_use_mu", C.c_int32),
@@ -126,6 +127,8 @@ def load():
     lib.nm_forward.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_head_regression.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_head_classifier.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.nm_train_steps_head.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.nm_train_steps_head.restype = i32
     lib.nm_posthoc_metrics.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.nm_confusion_metrics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.nm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp]
@@ -148,7 +151,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
     "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
 ]

@@ -599,17 +599,12 @@ class cVAE_multimodal_regression(_HeadBase):
 
     def _backward_native(self, g: float):
         j = self._job
-        ra = j.tables[0].rows_alloc
-        for k, (m, _, _) in enumerate(j.kmods):
-            j.dloc_extra[k] = torch.zeros(ra, j.tables[m].x_pitch, device=self._device)
         j.reg_lambda = self._lambda * g
         j.kl_weight, j.ll_weight = self._kl_weight * g, g
         j.step = 0
         j.touch()
-        js = JobSet([j])
-        js.head_regression(backward=True, grads=True)                                   # head: d MSE/d x_hat + its grads
-        js._launch(0, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS)                       # trunk: ELBO + extra
-        j.dloc_extra = [None] * len(j.kmods)
+        # one launch: trunk forward (same draws), head forward / backward, trunk backward with d MSE / d x_hat
+        JobSet([j]).grads_head(0)
         j.kl_weight, j.ll_weight = self._kl_weight, 1.0
         j.touch()
         self._pending = j.grads

@@ -662,15 +662,14 @@ __device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& n
 // images (xb chunk [256][LDX], weight chunk [128][LDX]); two stages (one in P, one in Q: both are dead here), so
 // chunk i + 1 is in flight while chunk i is multiplied.  The last chunk sits in P; `nx` (the next layer's image,
 // into Q) is requested as soon as the Q stage is drained.
-__device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const nm_modality_t& md, const GAS char* wsh, const Next& nx,
+// (xsrc: the tile's chunk images [nch][256][LDX]; wsrc: the layer's chunk images [nch][128][LDX] followed by the bias
+//  piece.  The trunk's encoders and the regression head's first layer both run through here.)
+__device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const GAS char* xsrc, int Kx, const GAS char* wsrc, const Next& nx,
                                                 int N, bool act, gbf16 save) {
   Ctx c = cc;
   relaunder(c);
-  const int Kx = md.Kx;
   const int nch = (Kx + XCH - 1) / XCH;
   const int ntn = wpad(N) / 16;
-  const GAS char* xsrc = (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * nch * XIMG_BYTES;
-  const GAS char* wsrc = wsh + md.enc_s[0];
   float* bias = c.vec + (VEC_BYTES / 4);            // slot 1 (slot 0 receives nx's vectors)
   auto stage = [&](int i) { return reinterpret_cast<char*>(((nch - 1 - i) & 1) ? c.Q : c.P); };
   auto issue_chunk = [&](int i) {
@@ -1041,6 +1040,13 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
 
 // ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
 __device__ __forceinline__ int experts(const nm_job_t* J) { return J->M_enc > 0 ? J->M_enc : J->M; }
+// Regression head: its first layer sees the residuals of the first `experts` modalities side by side, every modality
+// padded to whole 64-column chunks (nm_job_t.reg_w): chunks of modality m start at chunk head_chunk0(J, m).
+__host__ __device__ inline int head_chunk0(const nm_job_t* J, int m) {
+  int q = 0;
+  for (int i = 0; i < m; ++i) q += (J->mod[i].D + XCH - 1) / XCH;
+  return q;
+}
 struct Fuse { float mu, lv, var; };
 struct Lat { float mu[NM_MAX_EXP], lv[NM_MAX_EXP]; };     // always indexed by unrolled constants
 __device__ __forceinline__ void softmax_alpha(const nm_job_t* J, float (&al)[NM_MAX_EXP]) {
@@ -1166,14 +1172,19 @@ __device__ __forceinline__ float pick(const float (&a)[NM_MAX_EXP], int m) {
 // ----------------------------------------------------------------------------------------------
 // The step: all phases for one tile of 256 rows.
 // ----------------------------------------------------------------------------------------------
-template <bool SCALAR_TR>
+// MODE 0: the whole step.  Head models (regression / end-to-end, nm_head_step_kernel) run it as two passes around the
+// head: MODE 1 = encoders, fusion and every decoder forward (exports on; all activations incl. every decoder's last
+// hidden one saved), MODE 2 = the decoders' output chunks again from the saved activation -- now with the head's extra
+// gradients -- and the whole backward; no second encoder / fusion / hidden-decoder forward.
+template <bool SCALAR_TR, int MODE = 0>
 __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const nm_job_t* J = c.job;
   const int M = J->M, L = J->L, Z = J->Z, C = J->C;
   const int Me = experts(J);                    // modalities that have an encoder
   const bool nl = J->non_linear != 0;
-  const bool bwd = (c.flags & NM_F_BACKWARD) != 0;
-  const bool exportf = (c.flags & NM_F_EXPORT) != 0;
+  const bool bwd = MODE != 1 && (c.flags & NM_F_BACKWARD) != 0;
+  const bool save = bwd || MODE == 1;           // activations go to the workspace
+  const bool exportf = MODE != 2 && (c.flags & NM_F_EXPORT) != 0;
   const WsLayout wl = ws_layout(M, L, Z);
   const int Zs = wl.Zs;
   const bool split = c.part >= 0;               // this workgroup runs one modality of the model (NM_F_SPLIT)
@@ -1188,8 +1199,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   gf32 ws_es = (gf32)(c.ws + wl.es + part * wl.lat);
   gf32 ws_dz0 = (gf32)(c.ws + wl.dz);            // d z of decoder m at + m * 256 * Zs (one copy per decoder)
   GAS char* ws_enc = c.ws + wl.enc_act;         // activation images [256][LDP], ACT_BYTES each
-  GAS char* ws_dec = c.ws + wl.dec_act + (int64_t)part * L * wl.act;
-  GAS char* ws_zc = c.ws + wl.zc + part * wl.act;
+  GAS char* ws_dec0 = c.ws + wl.dec_act + (int64_t)part * L * wl.act;
+  GAS char* ws_zc0 = c.ws + wl.zc + part * wl.act;
   GAS unsigned* sync_a = (GAS unsigned*)(c.ws + wl.sync);
   GAS unsigned* sync_b = sync_a + 16;
   GAS unsigned* sync_err = sync_a + 32;
@@ -1200,26 +1211,27 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   char* const Pb = reinterpret_cast<char*>(c.P);
 
   // ================= encoders =================
-  for (int m = 0; m < Me; ++m) {
+  for (int m = 0; m < (MODE == 2 ? 0 : Me); ++m) {
     if (split && m != part) continue;
     relaunder(c);
     const nm_modality_t& md = J->mod[m];
-    gbf16 save0 = bwd ? (gbf16)(ws_enc + (int64_t)(m * L + 0) * ACT_BYTES) : (gbf16)nullptr;
+    gbf16 save0 = save ? (gbf16)(ws_enc + (int64_t)(m * L + 0) * ACT_BYTES) : (gbf16)nullptr;
     // the image of the phase after the first layer goes to the lower half of Q
     const GAS char* after0 = wsh + (L > 1 ? md.enc_s[1] : md.heads_s);
-    fwd_first_layer(c, md, wsh, blob_to_half(c, after0, 0), J->H[0], nl, save0);
+    fwd_first_layer(c, (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * ((md.Kx + XCH - 1) / XCH) * XIMG_BYTES, md.Kx,
+                    wsh + md.enc_s[0], blob_to_half(c, after0, 0), J->H[0], nl, save0);
     prof(c, PH_ENC_L0);
     int half = 0;
     for (int e = 1; e < L; ++e) {
-      gbf16 sv = bwd ? (gbf16)(ws_enc + (int64_t)(m * L + e) * ACT_BYTES) : (gbf16)nullptr;
+      gbf16 sv = save ? (gbf16)(ws_enc + (int64_t)(m * L + e) * ACT_BYTES) : (gbf16)nullptr;
       const GAS char* nxt = wsh + (e + 1 < L ? md.enc_s[e + 1] : md.heads_s);
-      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1), J->H[e], J->H[e - 1], nl, sv, bwd ? ACT_STORES : 0);
+      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1), J->H[e], J->H[e - 1], nl, sv, save ? ACT_STORES : 0);
       half ^= 1;
     }
     tr(c, 1);
     prof(c, PH_ENC_REST);
     fwd_heads(c, half, no_next(), Z, J->H[L - 1], ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs,
-              bwd ? ACT_STORES : 0);
+              save ? ACT_STORES : 0);
     prof(c, PH_HEADS);
   }
 
@@ -1228,7 +1240,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   if (split) split_handoff(c, sync_a, sync_err, sync_target);
   else handoff_barrier();
   // first decoder layer's image: requested now, lands during the latent arithmetic
-  issue_next(c, blob_to_half(c, wsh + J->mod[split ? part : 0].dec_s[0], 0));
+  if (MODE != 2) issue_next(c, blob_to_half(c, wsh + J->mod[split ? part : 0].dec_s[0], 0));
   float al[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
   if (J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass)) softmax_alpha(J, al);
   auto load_lat = [&](Lat& Lt, int r, int z) {
@@ -1244,7 +1256,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // posterior's half of it is a scalar minus its own mean, identically zero.  One wave per (expert, latent column):
   // max and sum over the rows by shuffles (fixed order), kept in LDS for the backward pass.
   float tc = 0.f;
-  if (J->tc_weight != 0.f) {
+  if (MODE != 2 && J->tc_weight != 0.f) {
     relaunder(c);
     for (int col = c.wave; col < Me * Z; col += NWAVES) {
       const int m = col / Z, z = col - m * Z;
@@ -1283,7 +1295,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   relaunder(c);
   // shared latent column z = head column S + z
 #pragma unroll 2
-  for (int e = c.tid; e < ROWS * Zc; e += WG) {
+  for (int e = c.tid; e < (MODE == 2 ? 0 : ROWS * Zc); e += WG) {
     int r = idiv(e, Zc, rZc), z = e - r * Zc;
     Lat Lt;
     load_lat(Lt, r, S + z);
@@ -1306,7 +1318,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       }
     }
   }
-  float kl = block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
+  float kl = (MODE == 2) ? 0.f : block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
   handoff_barrier();                                   // mu_j / es are complete for build_zc
   tr(c, 3);
   prof(c, PH_LATENT);
@@ -1319,31 +1331,41 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const nm_modality_t& md = J->mod[m];
     const int D = md.D;
     const int Kd0 = Z + C;
-    if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
+    const int nck = (D + OCH - 1) / OCH;
+    const GAS char* oblob = wsh + md.out_s;
     // z | c | 1: built by the first decoder; the others reuse it when all tables carry the same covariates
     const bool reuse_zc = J->shared_cov && M > 1 && !split && S == 0;
+    // (two-pass modes: every decoder keeps its own activations -- and its own z | c | 1 unless that one is shared)
+    GAS char* const ws_dec = ws_dec0 + (MODE != 0 ? (int64_t)m * L * wl.act : 0);
+    GAS char* const ws_zc = ws_zc0 + ((MODE != 0 && !reuse_zc) ? (int64_t)m * wl.act : 0);
+    if (MODE == 2) {
+      // second pass: the last hidden activation comes back from the workspace, chunk 0 of the output layer with it
+      lds_barrier();                                   // P / S are drained by whatever ran before
+      dma_lin(c, ws_dec + (int64_t)(L - 1) * ACT_BYTES, Pb, ACT_BYTES >> 10);
+      dma_lin(c, oblob, Sb, OBLOB_BYTES >> 10);
+    } else {
+    if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
     if (m == 0 || !reuse_zc) {
       build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs, S, ws_mu_m + (int64_t)min(m, Me - 1) * ROWS * Zs);
       lds_barrier();
-      if (bwd || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P);
+      if (save || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P);
     } else {
       dma_lin(c, ws_zc, Pb, ACT_BYTES >> 10);          // waited for by the first layer (it waits for everything older)
     }
     tr(c, 4);
     prof(c, PH_DEC_ZC);
     // --- hidden decoder layers; the last one requests output chunk 0 into slot B (= S) ---
-    const int nck = (D + OCH - 1) / OCH;
-    const GAS char* oblob = wsh + md.out_s;
     int half = 0;
     for (int d = 0; d < L; ++d) {
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
-      gbf16 sv = (bwd && d < L - 1) ? (gbf16)(ws_dec + (int64_t)d * ACT_BYTES) : (gbf16)nullptr;
+      gbf16 sv = (save && (d < L - 1 || MODE == 1)) ? (gbf16)(ws_dec + (int64_t)d * ACT_BYTES) : (gbf16)nullptr;
       Next nx = (d + 1 < L) ? blob_to_half(c, wsh + md.dec_s[d + 1], half ^ 1)
                             : Next{oblob, Sb, OBLOB_BYTES >> 10, nullptr, nullptr};
       // (d == 0: the z | c | 1 build / reload sits between the image request and here -- wait for everything)
-      fwd_layer(c, half, nx, Nout, Kin, nl, sv, (d > 0 && bwd) ? ACT_STORES : 0);
+      fwd_layer(c, half, nx, Nout, Kin, nl, sv, (d > 0 && save) ? ACT_STORES : 0);
       half ^= 1;
+    }
     }
     tr(c, 5);
     prof(c, PH_DEC_HID);
@@ -1367,6 +1389,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     // (tools/check_spill_exec.py)
     const float ll_w = (J->w_off >= 0) ? asg(J->params)[J->w_off + m] : J->ll_weight;
     const float llw_b = ll_w * c.inv_b;
+    // regression head: residual chunk images out (export), d loss / d x_hat chunk images in (second pass)
+    const int hq_all = (J->reg_head && m < Me) ? head_chunk0(J, Me) : 0;
+    const int64_t hq_m = (J->reg_head && m < Me) ? head_chunk0(J, m) : 0;
+    GAS char* const res_out = (exportf && hq_all > 0 && J->reg_resid)           // (one set of images per 256-row tile)
+        ? (GAS char*)asg(J->reg_resid) + ((int64_t)(c.row0 / ROWS) * hq_all + hq_m) * XIMG_BYTES : (GAS char*)nullptr;
+    const GAS char* const dres_in = (MODE == 2 && hq_all > 0 && J->reg_dres)    // (one set: the batch in flight)
+        ? (const GAS char*)asg(J->reg_dres) + hq_m * XIMG_BYTES : (const GAS char*)nullptr;
     for (int ch = 0; ch < nck; ++ch) {
       relaunder(c);
       const int d0 = ch * OCH;
@@ -1398,6 +1427,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
           xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
+      }
+      bf16x4 exh[RT];                               // the head's gradient on this lane's 4 x RT outputs (second pass only)
+      if (MODE == 2 && dres_in) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          exh[rt] = *(const GAS bf16x4*)(dres_in + (int64_t)ch * XIMG_BYTES + ((c.wm * WROWS + rt * 16 + c.c16) * LDX + dl0) * 2);
       }
 #if NM_PRE_OUT == 2
       if (adam_on && c.wave < wg_units(Go)) wg_request(c, Go, c.wave, pm_a);
@@ -1455,8 +1490,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           }
           bf16x4 pk;
           f32x4 ex = {0.f, 0.f, 0.f, 0.f};
-          if (md.dloc_extra)               // extra loss gradient on x_hat (regression head)
+          if (md.dloc_extra)               // extra loss gradient on x_hat
             ex = *(const GAS f32x4*)(asg(md.dloc_extra) + (int64_t)(c.row0 + r) * xp + min(dg0, xp - 4));
+          if (MODE == 2 && dres_in) {      // ... of the regression head (bf16 chunk image, requested before the GEMM)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[i] += (float)exh[rt][i];
+          }
           float rc = 0.f;
           if (md.dloc_rowcoef) rc = asg(md.dloc_rowcoef)[c.row0 + r];      // contrastive hinge: rc * (x_hat - x)
 #pragma unroll
@@ -1467,6 +1506,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
             pk[i] = (__bf16)((diff * (coef[i] + (dv ? rc : 0.f)) + ((rv && dv) ? ex[i] : 0.f)) * dsig[i]);
           }
           if (bwd) *reinterpret_cast<bf16x4*>(Dq + r * LDX + dl0) = pk;
+          if (res_out) {                   // x - x_hat, zero on pad rows / columns: the head's first-layer operand
+            bf16x4 rk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rk[i] = (__bf16)((rv && dg0 + i < D) ? xin[rt][i] - acc[rt][i] : 0.f);
+            *(GAS bf16x4*)(res_out + (int64_t)ch * XIMG_BYTES + (r * LDX + dl0) * 2) = rk;
+          }
         }
         float colsum[4];
 #pragma unroll
@@ -1492,8 +1537,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
                 rs += sq[i];
               }
               const int64_t gi = (int64_t)(c.row0 + r) * xp + dg0;
-              if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
-              if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
+              if (MODE == 1) {                    // read back by the head phase of this workgroup
+                if (md.out_loc) *(GAS f32x4*)(asg(md.out_loc) + gi) = lo;
+                if (md.out_sqerr) *(GAS f32x4*)(asg(md.out_sqerr) + gi) = sq;
+              } else {
+                if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
+                if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
+              }
               if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
             }
           }
@@ -1610,7 +1660,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // d z (and, split: ll_m) of every decoder is complete
   if (split) split_handoff(c, sync_b, sync_err, sync_target);
   else handoff_barrier();
-  if (c.tid == 0 && J->loss_log && part == 0) {
+  if (MODE != 2 && c.tid == 0 && J->loss_log && part == 0) {
     gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
     if (split) {                                  // the other parts logged their ll_m before they arrived
       ll_sum = 0.f;
@@ -1637,7 +1687,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const bool fused = !(Me == 1 && J->single_bypass);
   const float klw = kl_w * c.inv_b;
   const float tcw = J->tc_weight / (float)Me;     // (the softmax over the rows is normalised: no 1 / B)
-  gbf16 ws_fz = (gbf16)ws_zc;                     // the (dead) z|c slot, legacy [256][PW] layout
+  gbf16 ws_fz = (gbf16)ws_zc0;                    // the (dead) z|c slot, legacy [256][PW] layout
   // With several experts the fusion backward (8 exponentials per element) is evaluated ONCE: the deltas of every
   // expert go side by side into Q (expert m in columns [m 2Zs, (m+1) 2Zs) = [d mu_m | d logvar_m]), from there into
   // the (dead) z|c slot of the workspace, and each encoder's backward below starts from a 16-byte copy of its
@@ -1934,54 +1984,14 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
 
 // ---- regression head (cVAE.py:2249-2253 regressor, 2318-2321 forward, 2330-2346 loss) ----------------
 // fi_pred = W3 relu(W2 relu(W1 cat_m(x_m - x_hat_m) + b1) + b2) + b3;  loss = mean_r (fi_pred - FI)^2.
-// One workgroup per (job, 256-row tile); same operand conventions as the trunk: bf16 MFMA operands,
-// fp32 accumulate, fp32 parameters.  The concatenated residual [256][sum D] is walked in 128-column
-// chunks of the CONCATENATED column space (so chunk boundaries stay 16-byte aligned inside W1's rows);
-// a chunk may straddle two modalities.
-struct CatCol { int m, d; };
-__device__ __forceinline__ CatCol cat_col(const nm_job_t* J, int M, int col) {
-  CatCol r{0, col};
-#pragma unroll
-  for (int m = 0; m < NM_MAX_EXP - 1; ++m) {
-    const int Dm = J->mod[m].D;
-    if (m < M - 1 && r.m == m && r.d >= Dm) { r.m = m + 1; r.d -= Dm; }
-  }
-  return r;
-}
-// Q[r][j] = x[r][col] - x_hat[r][col] for concatenated column col = k0 + j < SD, valid rows; 0 elsewhere.
-// Walked per modality segment in the modality's own column space: x_f32 and the exported x_hat share the
-// row pitch x_pitch (a multiple of 4), so a group of four columns is two aligned 16-byte loads.
-__device__ __forceinline__ void resid_chunk_to_Q(const Ctx& c, int M, int SD, int k0) {
-  const nm_job_t* J = c.job;
-  int koff = 0;
-  for (int m = 0; m < M; ++m) {
-    const nm_modality_t& md = J->mod[m];
-    const int lo = max(0, k0 - koff), hi = min(md.D, k0 + PW - koff);     // this modality's columns inside the chunk
-    if (lo < hi) {
-      gcf32 xf = asg(md.x_f32);
-      gcf32 xh = asg((const float*)md.out_loc);
-      const int g0 = lo >> 2, ng = ((hi + 3) >> 2) - g0;
-      const float rng = 1.0f / (float)ng;
-      for (int e = c.tid; e < ROWS * ng; e += WG) {
-        const int r = idiv(e, ng, rng), d0 = 4 * (g0 + e - r * ng);
-        const int64_t o = (int64_t)(c.row0 + r) * md.x_pitch + d0;
-        const f32x4 xv = *(const GAS f32x4*)(xf + o), hv = *(const GAS f32x4*)(xh + o);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (d0 + i >= lo && d0 + i < hi) c.Q[r * LDP + koff + d0 + i - k0] = (__bf16)(r < c.nrows ? xv[i] - hv[i] : 0.f);
-      }
-    }
-    koff += md.D;
-  }
-  if (k0 + PW > SD) {                             // columns past the end of the concatenation
-    const int z0 = SD - k0, nz = PW - z0;
-    const float rz = 1.0f / (float)nz;
-    for (int e = c.tid; e < ROWS * nz; e += WG) {
-      const int r = idiv(e, nz, rz);
-      c.Q[r * LDP + z0 + (e - r * nz)] = (__bf16)0.0f;
-    }
-  }
-}
+// One workgroup per (job, 256-row tile); same operand conventions as the trunk: bf16 MFMA operands, fp32 accumulate,
+// fp32 parameters.  The first layer is the big one (128 x sum D) and runs like the trunk's first encoder layer: the
+// trunk's output chunks leave the residual as bf16 chunk images [256][72] (nm_job_t.reg_resid, one per 64 ROI columns
+// of a modality), W1 lives in the master with every modality's columns padded to whole chunks and has bf16 chunk
+// images [128][72] in the shadow (nm_job_t.reg_s); forward = both streamed through LDS by LDS-DMA, two stages;
+// backward per chunk = weight gradient + Adam in wave-independent units from the residual image, then
+// d loss / d x_hat = -(delta h1 W1[:, chunk]) from the (pre-update) weight image, written as a bf16 chunk image
+// (nm_job_t.reg_dres) that the trunk's second pass adds to its NLL gradient.
 // P[r][f] = relu(acc) for f < N (N a multiple of 16, <= 128)
 __device__ __forceinline__ void relu_to_P(const Ctx& c, const f32x4 (&acc)[2][RT], int N) {
 #pragma unroll
@@ -1999,14 +2009,12 @@ __device__ __forceinline__ void relu_to_P(const Ctx& c, const f32x4 (&acc)[2][RT
   }
 }
 
-__global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const nm_job_t* J = jobs + blockIdx.x;
-  Ctx c;
+// Set-up shared by the stand-alone head kernels: LDS carved and zeroed, the tile's rows, Adam scalars of `step`.
+__device__ __forceinline__ bool head_setup(Ctx& c, unsigned char* smem, const nm_job_t* J, int step, int tile0, int flags) {
   c.job = J;
   carve_lds(c, smem);
   relaunder(c);
-  c.flags = flags & ~(NM_F_PROFILE | NM_F_TRACE);
+  c.flags = flags;
   c.part = -1; c.nparts = 1; c.lstep = 0; c.slope = J->act_slope;
   c.t_last = 0;
   c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
@@ -2014,62 +2022,45 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   __syncthreads();
   c.row0 = (tile0 + (int)blockIdx.y) * ROWS;
   c.nrows = min(ROWS, J->n_rows - c.row0);
-  if (c.nrows <= 0) return;
+  if (c.nrows <= 0) return false;
   c.inv_b = 1.0f / (float)c.nrows;
   const int64_t t_opt = J->adam_off + (int64_t)step + 1;
   const double tt = (double)t_opt;
   const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
   c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
   c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+  return true;
+}
+
+// The head of one 256-row tile; `c` is fully set up (rows, Adam scalars, c.flags = NM_F_BACKWARD / ADAM / GRADS).
+// `hws` = the head's own workspace (behind the trunk's: the trunk's saved activations stay intact); `log` = this
+// tile writes the loss row.  Leaves LDS in an arbitrary (finite) state.
+__device__ __forceinline__ void reg_head_body(Ctx& c, const nm_job_t* J, int step, GAS char* hws, bool log) {
+  const int flags = c.flags;
   const bool bwd = (flags & NM_F_BACKWARD) != 0;
   const int M = experts(J);
-  int SD = 0;
-  for (int m = 0; m < M; ++m) SD += J->mod[m].D;
   constexpr int N1 = 128, N2 = 64;
+  const int nq = head_chunk0(J, M), Kh = nq * XCH;           // chunks / columns of the padded concatenation
   gcf32 prm = asg(J->params);
-  gcf32 W1 = prm + J->reg_w[0], b1 = prm + J->reg_b[0], W2 = prm + J->reg_w[1], b2 = prm + J->reg_b[1];
-  gcf32 W3 = prm + J->reg_w[2];
-  const WsLayout wl = ws_layout(J->M, J->L, J->Z);
-  // the trunk's workspace is dead between its two launches: h1 first, then the residual chunks (bf16), kept for
-  // the backward pass so that x / x_hat are read once
-  gbf16 ws_h1 = (gbf16)c.ws;
-  gbf16 ws_res = (gbf16)(c.ws + (int64_t)ROWS * PW * 2);
-  (void)wl;
-  const int nch = (SD + PW - 1) / PW;
+  gcf32 W2 = prm + J->reg_w[1], b2 = prm + J->reg_b[1], W3 = prm + J->reg_w[2];
+  GAS char* const wimg = (GAS char*)J->wsh + J->reg_s;       // W1 chunk images, then b1
+  const int64_t tile_off = (int64_t)(c.row0 / ROWS) * nq * XIMG_BYTES;
+  const GAS char* const res = (const GAS char*)asg(J->reg_resid) + tile_off;
+  GAS char* const dres = (GAS char*)asg(J->reg_dres);        // (one set of images: the batch in flight)
+  gbf16 ws_h1 = (gbf16)hws;                                  // h1 as an activation image (backward)
+  char* const Qb = reinterpret_cast<char*>(c.Q);
+  char* const Pb = reinterpret_cast<char*>(c.P);
+  const float slope_keep = c.slope;
+  c.slope = 0.f;                                             // ReLU
 
-  // ---- layer 1: h1 = relu(W1 resid + b1): the residual streamed through Q, the matching 128-column block of
-  // W1 through P (free until h1 exists), both as coalesced copies; next block's weights fly during the MFMAs ----
-  f32x4 acc[2][RT];
-  bias_acc(c, acc, b1, N1, 0);
-  const int Kp1 = SD;                            // wblk_* take the matrix's K (tiled master)
-  WBlk<128> wb;
-  wblk_load<128>(c, wb, W1, N1, Kp1, 0, 0);
-  for (int ch = 0; ch < nch; ++ch) {
-    relaunder(c);
-    const int k0 = ch * PW, valid = min(PW, SD - k0), ksteps = rup(valid, 32) / 32;
-    resid_chunk_to_Q(c, M, SD, k0);
-    wblk_store<128>(c, wb, c.P, LDP, N1, Kp1, 0, k0);
-    lds_barrier();
-    if (ch + 1 < nch) wblk_load<128>(c, wb, W1, N1, Kp1, 0, k0 + PW);
-    if (bwd) store_act(c, ws_res + (int64_t)ch * ROWS * PW, c.Q, PW);
-    for (int ks = 0; ks < ksteps; ++ks) {
-      bf16x8 wf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.P, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        bf16x8 a = lds_frag(c.Q, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t][rt] = mfma(wf[t], a, acc[t][rt]);
-      }
-    }
-    lds_barrier();
-  }
-  relu_to_P(c, acc, N1);
-  lds_barrier();
-  if (bwd) store_act(c, ws_h1, c.P, N1);
+  // ---- layer 1: h1 = relu(W1 resid + b1) ----
+  lds_barrier();                                             // P / Q are drained by whatever ran before
+  fwd_first_layer(c, res, Kh, wimg, no_next(), N1, true, bwd ? ws_h1 : (gbf16)nullptr);
+  c.slope = slope_keep;
+  tr(c, 21);
   // ---- layer 2: h2 = relu(W2 h1 + b2), in place ----
   relaunder(c);
+  f32x4 acc[2][RT];
   bias_acc(c, acc, b2, N2, 0);
   for (int ks = 0; ks < N1 / 32; ++ks) {
     bf16x8 wf[2];
@@ -2098,8 +2089,9 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
     }
   }
   const float sse = block_sum(c, err * err);
-  if (c.tid == 0 && J->loss_log && J->fi_target && blockIdx.y == 0)   // one tile's MSE (training: the step's batch)
+  if (c.tid == 0 && J->loss_log && J->fi_target && log)   // one tile's MSE (training: the step's batch)
     asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_REG] = sse * c.inv_b;
+  tr(c, 22);
   if (!bwd) return;
 
   // ---- backward ----
@@ -2127,7 +2119,8 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
     apply_grad(c, J->reg_b[1] + c.tid, g);
   }
   // layer 2 backward: Q <- h1; delta h1 (pre-mask) = delta h2 W2; dW2 = delta h2^T h1
-  load_act(c, c.Q, ws_h1, N1);
+  dma_lin(c, (const GAS char*)ws_h1, Qb, ACT_BYTES >> 10);
+  wait_vm(0);
   lds_barrier();
   zero_acc(acc);
   dgrad_acc(c, acc, c.P, W2, N2, N1, N2 / 32, 0);
@@ -2149,51 +2142,67 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
     }
   }
   lds_barrier();
-  if (c.tid < N1) {                              // db1
-    float g = 0.f;
-    for (int r = 0; r < ROWS; ++r) g += (float)c.P[r * LDP + c.tid];
-    apply_grad(c, J->reg_b[0] + c.tid, g);
-  }
-  // layer 1 backward per chunk: d resid = delta h1 W1 (-> dloc_extra = -d resid), dW1 chunk = delta h1^T resid
-  for (int ch = 0; ch < nch; ++ch) {
-    relaunder(c);
-    const int k0 = ch * PW, valid = min(PW, SD - k0);
-    // the W1 block of this chunk comes as two 64-row half tiles through the gradient slab (transposing reads)
-    __bf16* Th = reinterpret_cast<__bf16*>(c.stage);
-    WBlk<64> ha, hb;
-    wblk_load<64>(c, ha, W1, N1, Kp1, 0, k0);
-    wblk_load<64>(c, hb, W1, N1, Kp1, 64, k0);
-    load_act(c, c.Q, ws_res + (int64_t)ch * ROWS * PW, PW);
-    wblk_store<64>(c, ha, Th, LDP, N1, Kp1, 0, k0);
-    lds_barrier();
-    zero_acc(acc);
-    dgrad_tile(c, acc, c.P, LDP, 0, Th, LDP, 2);
-    lds_barrier();
-    wblk_store<64>(c, hb, Th, LDP, N1, Kp1, 64, k0);
-    lds_barrier();
-    dgrad_tile(c, acc, c.P, LDP, 64, Th, LDP, 2);
+  tr(c, 23);
+  // ---- layer 1 backward ----
+  // LDS: P = delta h1; Q = [residual chunk [256][72] | W1 chunk slot A [128][72] | slot B] (slot B runs 4 KiB into S,
+  // below the patches).  Per chunk: weight gradient + Adam from the residual image (the LDS copy of the chunk's
+  // weights was complete before: the dgrad below sees the weights of THIS step), the next residual chunk is requested
+  // as soon as every wave is done with the current one, then d loss / d x_hat = -(delta h1 W1[:, chunk]).
+  {
+    char* const slotR = Qb;
+    auto slotW = [&](int q) { return Qb + XIMG_BYTES + (q & 1) * W0IMG_BYTES; };
+    dma_lin(c, res, slotR, XIMG_BYTES >> 10);
+    dma_lin(c, wimg, slotW(0), W0IMG_BYTES >> 10);
+    if (c.tid < N1) {                              // db1 (and its fp32 copy behind the chunk images)
+      float g = 0.f;
+      for (int r = 0; r < ROWS; ++r) g += (float)c.P[r * LDP + c.tid];
+      apply_grad(c, J->reg_b[0] + c.tid, g, (GAS float*)(wimg + (int64_t)nq * W0IMG_BYTES) + c.tid);
+    }
+    for (int q = 0; q < nq; ++q) {
+      relaunder(c);
+      wait_vm(0);
+      lds_barrier();                               // chunk q's residual and weights have landed everywhere
+      if (q + 1 < nq) dma_lin(c, wimg + (int64_t)(q + 1) * W0IMG_BYTES, slotW(q + 1), W0IMG_BYTES >> 10);
+      wgrad_adam<false>(c, c.P, LDP, 0, reinterpret_cast<const __bf16*>(slotR), LDX,
+                        WgGeom{N1, Kh, q * XCH, XCH, WgT{J->reg_w[0], -1, wimg + (int64_t)q * W0IMG_BYTES, LDX * 2, nullptr, hpatch}});
+      tr(c, 24);
+      if (q + 1 < nq) dma_lin(c, res + (int64_t)(q + 1) * XIMG_BYTES, slotR, XIMG_BYTES >> 10);
+      // d resid chunk: lane (c16, g) of row tile rt holds columns wn * 16 + 4 g .. + 3 of row wm * 128 + rt * 16 + c16
+      const __bf16* Wq = reinterpret_cast<const __bf16*>(slotW(q));
+      f32x4 dr[RT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+      for (int rt = 0; rt < RT; ++rt) dr[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < N1 / 32; ++s) {
+        bf16x4 l0, h0;
+        const unsigned a0 = tr_addr(Wq, LDX, s * 32, c.wn * 16, c.lane);
+        NM_TR_READ(l0, a0, 0); NM_TR_READ(h0, a0 + 4u * LDX * 2u, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(h0));
+        const bf16x8 wf = join4(l0, h0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int col = k0 + (c.wn + 4 * t) * 16 + 4 * c.g + i;
-        if (col < SD) {
-          const CatCol cc = cat_col(J, M, col);
-          const nm_modality_t& md = J->mod[cc.m];
-          if (md.dloc_extra) {
-            gf32 dst = asg((float*)md.dloc_extra);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-              const int r = c.wm * WROWS + rt * 16 + c.c16;
-              if (r < c.nrows) dst[(int64_t)(c.row0 + r) * md.x_pitch + cc.d] = -acc[t][rt][i];
-            }
-          }
+        for (int rt = 0; rt < RT; ++rt) {
+          bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, s * 32 + 8 * c.g);
+          dr[rt] = mfma(wf, a, dr[rt]);
         }
       }
+      const int dl0 = c.wn * 16 + 4 * c.g;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = c.wm * WROWS + rt * 16 + c.c16;
+        bf16x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(-dr[rt][i]);                 // d / d x_hat = - d / d resid
+        *(GAS bf16x4*)(dres + (int64_t)q * XIMG_BYTES + (r * LDX + dl0) * 2) = pk;
+      }
+      tr(c, 25);
     }
-    lds_barrier();                               // W1 chunk fully read before its update
-    wgrad_adam<false>(c, c.P, LDP, 0, c.Q, LDP, WgGeom{N1, SD, k0, rup(valid, 16), WgT{J->reg_w[0], -1, nullptr, 0, nullptr, hpatch}});
   }
+}
+__global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const nm_job_t* J = jobs + blockIdx.x;
+  Ctx c;
+  if (!head_setup(c, smem, J, step, tile0, flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return;
+  reg_head_body(c, J, step, c.ws + ws_layout(J->M, J->L, J->Z).total, blockIdx.y == 0);
 }
 
 // ---- classifier head of the end-to-end model (cVAE.py:2004-2018 Classifier, 2117 logits, 2140-2200 loss) ---
@@ -2229,28 +2238,9 @@ __device__ __forceinline__ float uniform_ctr(uint64_t seed, uint32_t step, uint3
   return (uint32_t)(h >> 40) * (1.0f / 16777216.0f);
 }
 
-__global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const nm_job_t* J = jobs + blockIdx.x;
-  Ctx c;
-  c.job = J;
-  carve_lds(c, smem);
-  relaunder(c);
-  c.flags = flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS);
-  c.part = -1; c.nparts = 1; c.lstep = 0; c.slope = J->act_slope;
-  c.t_last = 0;
-  c.ws = (GAS char*)J->workspace + (int64_t)blockIdx.y * J->workspace_stride;
-  for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
-  __syncthreads();
-  c.row0 = (tile0 + (int)blockIdx.y) * ROWS;
-  c.nrows = min(ROWS, J->n_rows - c.row0);
-  if (c.nrows <= 0) return;
-  c.inv_b = 1.0f / (float)c.nrows;
-  const int64_t t_opt = J->adam_off + (int64_t)step + 1;
-  const double tt = (double)t_opt;
-  const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
-  c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
-  c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+// (same contract as reg_head_body; `bn_stats`: update the BatchNorm running statistics)
+__device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int step, GAS char* hws, bool log, bool bn_stats) {
+  const int flags = c.flags;
   const bool train = J->cls_train != 0;
   const bool bwd = (flags & NM_F_BACKWARD) != 0 && train && J->labels != nullptr;
   const int Lc = J->cls_layers, C = J->cls_classes, Z = J->Z;
@@ -2260,7 +2250,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   float* col2 = c.stage;
   ClsWs W;
   {
-    GAS char* p = c.ws;
+    GAS char* p = hws;
     for (int i = 0; i <= NM_MAX_CLS; ++i) { W.hin[i] = (gbf16)p; p += (int64_t)ROWS * PW * 2; }
     for (int i = 0; i < NM_MAX_CLS; ++i) { W.xhat[i] = (gf32)p; p += (int64_t)ROWS * PW * 4; }
     for (int i = 0; i < NM_MAX_CLS; ++i) { W.rstd[i] = (gf32)p; p += (int64_t)PW * 4; }
@@ -2347,7 +2337,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
     if (c.tid < N && train) {                      // per-feature rstd for the backward pass; running statistics
       const float m = col1[c.tid] / Bf, var = col2[c.tid] / Bf;
       if (bwd) W.rstd[li][c.tid] = 1.0f / sqrtf(var + 1e-5f);
-      if ((flags & NM_F_BNSTATS) && blockIdx.y == 0) {
+      if (bn_stats && log) {
         gf32 rm = asg(J->params) + J->cls_bn_mean[li] + c.tid, rv = asg(J->params) + J->cls_bn_var[li] + c.tid;
         const float unb = c.nrows > 1 ? var * Bf / (Bf - 1.0f) : var;      // running_var takes the unbiased estimate
         *rm = 0.9f * *rm + 0.1f * m;
@@ -2379,6 +2369,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
     lds_barrier();
   }
 
+  tr(c, 26);
   // ---- output layer, cross entropy ----
   relaunder(c);
   const int Kl = Lc ? J->cls_width[Lc - 1] : Z, Kl32 = rup(Kl, 32);
@@ -2455,11 +2446,12 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
     }
   }
   const float hinge_sum = block_sum(c, hinge);
-  if (c.tid == 0 && J->loss_log && J->labels && blockIdx.y == 0) {
+  if (c.tid == 0 && J->loss_log && J->labels && log) {
     gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
     row[NM_LOSS_CE] = ce_sum * c.inv_b;
     row[NM_LOSS_CONTRAST] = hinge_sum * c.inv_b;
   }
+  tr(c, 27);
   if (!bwd) return;
 
   // ---- backward: output layer ----
@@ -2562,6 +2554,70 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
     }
   }
 }
+__global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const nm_job_t* J = jobs + blockIdx.x;
+  Ctx c;
+  if (!head_setup(c, smem, J, step, tile0, flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return;
+  cls_head_body(c, J, step, c.ws + ws_layout(J->M, J->L, J->Z).total, blockIdx.y == 0, (flags & NM_F_BNSTATS) != 0);
+}
+
+// ---- head models in one persistent launch ------------------------------------------------------------------------
+// One workgroup per model, n_steps train steps of a regression / end-to-end model (the loops of
+// multimodal_kfold_train_cvae_supervised_regression.py:112-125 and multimodal_kfold_cvae_nmpmcont.py:257-303), per step:
+//   pass 1  trunk forward: encoders, fusion, every decoder; reconstructions / latent / per-subject deviations exported,
+//           every activation saved (run_step MODE 1);
+//   head    forward, its loss, backward, its Adam update; d loss / d x_hat (regression) or d CE / d z and the hinge row
+//           coefficients (classifier) left in the job's exchange buffers;
+//   pass 2  per decoder: output chunks again from the saved last hidden activation, now with those extra gradients,
+//           NLL backward, dgrad, wgrad + Adam; then the decoders' hidden layers, fusion and encoders backward (MODE 2).
+// The trunk's forward runs once (the three-launch form ran it twice), nothing returns to the host between steps.
+__global__ __launch_bounds__(WG) void nm_head_step_kernel(const nm_job_t* __restrict__ jobs, int step0, int n_steps, int flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const nm_job_t* J = jobs + blockIdx.x;
+  Ctx c;
+  c.job = J;
+  c.part = -1; c.nparts = 1; c.slope = J->act_slope;
+  carve_lds(c, smem);
+  relaunder(c);
+  c.t_last = 0;
+  c.ws = (GAS char*)J->workspace;
+  for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  __syncthreads();
+  GAS char* const hws = c.ws + ws_layout(J->M, J->L, J->Z).total;
+  const int nb = (J->n_rows + ROWS - 1) / ROWS;
+  const int tflags = flags & (NM_F_PROFILE | NM_F_TRACE);
+  // NM_F_GRADS: gradients of the step's total into job.grads, no update (the eager facade's backward)
+  const int bflags = NM_F_BACKWARD | ((flags & NM_F_GRADS) ? NM_F_GRADS : NM_F_ADAM);
+  for (int s = step0; s < step0 + n_steps; ++s) {
+    c.lstep = s - step0;
+    c.row0 = (s % nb) * ROWS;
+    c.nrows = min(ROWS, J->n_rows - c.row0);
+    c.inv_b = 1.0f / (float)c.nrows;
+    const int64_t t_opt = J->adam_off + (int64_t)s + 1;
+    const double tt = (double)t_opt;
+    const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
+    c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
+    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+    if (flags & 64) c.tlast[threadIdx.x >> 6] = clock64();
+    lds_barrier();
+    relaunder(c);
+    c.flags = NM_F_EXPORT | tflags;
+    run_step<false, 1>(c, s);
+    handoff_barrier();                            // exports and saved activations are complete
+    tr(c, 20);
+    relaunder(c);
+    c.flags = bflags | tflags;
+    if (J->reg_head) reg_head_body(c, J, s, hws, true);
+    else if (J->cls_classes > 0) cls_head_body(c, J, s, hws, true, (flags & NM_F_BNSTATS) != 0);
+    handoff_barrier();                            // the head's gradients for the trunk are complete
+    tr(c, 29);
+    relaunder(c);
+    c.flags = bflags | tflags;
+    run_step<false, 2>(c, s);
+    handoff_barrier();                            // the next step reads what this one stored
+  }
+}
 
 // ---- stand-alone kernels ----------------------------------------------------------------------
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -2639,6 +2695,12 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
       vb[i % OCH] = prm[md.out_b + i];
       if (J->out_kind == 0) vb[OCH + i % OCH] = prm[md.logvar_out + i];
     }
+  }
+  if (J->reg_head) {                               // regressor.0: chunk images [128][72] over the padded concatenation + bias
+    const int nq = head_chunk0(J, Me);
+    sync_matrix(prm, J->reg_w[0], 128, nq * XCH, wsh + J->reg_s, LDX * 2, XCH, W0IMG_BYTES, BIG, 0);
+    float* b = (float*)(wsh + J->reg_s + (int64_t)nq * W0IMG_BYTES);
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) b[i] = prm[J->reg_b[0] + i];
   }
 }
 
@@ -2830,7 +2892,7 @@ const char* nm_status_string(int status) {
     case -10: return "parameter tensor offsets must be multiples of 4 floats (weight matrices: of 256)";
     case -13: return "classifier head: 0..NM_MAX_CLS blocks of width 1..128, 2..NM_MAX_CLASSES classes, offsets multiples of 4, out_mu/out_z export";
     case -12: return "metrics: n_sets >= 1 and 1 <= max_set <= NM_METRICS_MAX_N";
-    case -11: return "regression head: needs reg_w / reg_b offsets (multiples of 4) and every expert's out_loc export";
+    case -11: return "regression head: needs reg_w / reg_b offsets (weights: multiples of 256, biases: of 4) and the reg_resid / reg_dres image buffers (16-byte aligned)";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
   }
 }
@@ -2875,8 +2937,7 @@ int nm_validate_job(const nm_job_t* j) {
   if (j->reg_head) {
     for (int i = 0; i < 3; ++i)
       if (j->reg_w[i] < 0 || j->reg_b[i] < 0 || (j->reg_w[i] & 255) || (j->reg_b[i] & 3)) return -11;
-    for (int m = 0; m < (j->M_enc == 0 ? j->M : j->M_enc); ++m)
-      if (!j->mod[m].out_loc) return -11;
+    if (!j->reg_resid || !j->reg_dres || ((uintptr_t)j->reg_resid & 15) || ((uintptr_t)j->reg_dres & 15)) return -11;
   }
   return 0;
 }
@@ -2900,6 +2961,8 @@ int64_t nm_fill_shadow(nm_job_t* j) {
     for (int d = 0; d < j->L; ++d) { md.dec_s[d] = o; o += BLOB_BYTES; }
     md.out_s = o; o += (int64_t)((md.D + OCH - 1) / OCH) * OBLOB_BYTES;
   }
+  j->reg_s = 0;
+  if (j->reg_head) { j->reg_s = o; o += (int64_t)head_chunk0(j, Me) * W0IMG_BYTES + VEC_BYTES; }
   return o;
 }
 
@@ -2912,15 +2975,11 @@ int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
 
 int64_t nm_workspace_bytes(const nm_job_t* j) {
   if (!j) return -1;
-  int64_t b = ws_layout(j->M, j->L, j->Z).total;
-  if (j->reg_head) {                      // regression head: h1 + one bf16 tile per 128 concatenated residual columns
-    int sd = 0;
-    for (int m = 0; m < (j->M_enc > 0 ? j->M_enc : j->M); ++m) sd += j->mod[m].D;
-    int64_t hb = (int64_t)(1 + (sd + PW - 1) / PW) * ROWS * PW * 2;
-    b = b > hb ? b : (hb + 255) / 256 * 256;
-  }
-  if (j->cls_layers > 0 || j->cls_classes > 0) b = b > cls_ws_bytes() ? b : (cls_ws_bytes() + 255) / 256 * 256;
-  return b;
+  int64_t b = ws_layout(j->M, j->L, j->Z).total;      // the head's region sits behind the trunk's
+  int64_t hb = 0;
+  if (j->reg_head) hb = ACT_BYTES;        // regression head: its first hidden activation, kept for the backward pass
+  if (j->cls_layers > 0 || j->cls_classes > 0) hb = hb > cls_ws_bytes() ? hb : cls_ws_bytes();
+  return b + (hb + 255) / 256 * 256;
 }
 
 static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
@@ -2993,6 +3052,19 @@ int nm_head_classifier(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nm_clshead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,
                      tile0, flags);
+  return (int)hipGetLastError();
+}
+
+/* n_steps train steps of head models (every job: regression head, or end-to-end with classifier, labels / targets and
+ * exchange buffers set) in ONE persistent launch, one workgroup per job: see nm_head_step_kernel. */
+int nm_train_steps_head(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, int flags, void* stream) {
+  if (!jobs_dev) return -1;
+  if (n_jobs < 1 || n_steps < 1 || step0 < 0) return -8;
+  hipError_t e = hipFuncSetAttribute((const void*)nm_head_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  if (e != hipSuccess) return (int)e;
+  if ((flags & NM_F_GRADS) && n_steps != 1) return -8;
+  hipLaunchKernelGGL(nm_head_step_kernel, dim3(n_jobs), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step0, n_steps,
+                     flags & (NM_F_PROFILE | NM_F_TRACE | NM_F_GRADS | NM_F_BNSTATS));
   return (int)hipGetLastError();
 }
 

@@ -145,6 +145,8 @@ class Job:
         self.reg_lambda = 1.0                         # regression head (kind == "regression")
         self.fi_target: Optional[torch.Tensor] = None # [rows_alloc]
         self.out_fi_pred: Optional[torch.Tensor] = None
+        self.reg_resid: Optional[torch.Tensor] = None # bf16 residual chunk images (nm_job_t.reg_resid)
+        self.reg_dres: Optional[torch.Tensor] = None  # bf16 d MSE / d x_hat chunk images of the batch in flight
         self.single_bypass = bool(single_bypass)
         self.seed = int(seed)
         self.t = 0                       # optimizer steps taken
@@ -224,12 +226,16 @@ class Job:
             self._version += 1
 
     def prepare_regression(self):
-        """Buffers the regression train loop needs: exported reconstructions and the d MSE / d x_hat slots."""
-        if any(o is None for o in self.out_loc) or self.out_fi_pred is None:
-            self.enable_exports(loc=True, sqerr=False, rowdev=False, latent=False)
-        if any(d is None for d in self.dloc_extra):
-            ra = self.tables[0].rows_alloc
-            self.dloc_extra = [torch.zeros(ra, self.tables[m].x_pitch, device=self.device) for m, _, _ in self.kmods]
+        """Buffers the regression head needs: the residual chunk images the trunk exports for it (one set per 256-row
+        tile of the table), the d MSE / d x_hat images it hands back (one set: the batch in flight), the predictions."""
+        nq = sum((self.tables[m].D + 63) // 64 for m in range(self.spec.M))
+        img = 256 * 72 * 2
+        if self.reg_resid is None or self.reg_resid.numel() < self.tables[0].n_tiles * nq * img:
+            self.reg_resid = torch.zeros(self.tables[0].n_tiles * nq * img, dtype=torch.uint8, device=self.device)
+            self.reg_dres = torch.zeros(nq * img, dtype=torch.uint8, device=self.device)
+            self._version += 1
+        if self.out_fi_pred is None:
+            self.out_fi_pred = torch.zeros(self.tables[0].rows_alloc, device=self.device)
             self._version += 1
 
     def touch(self):
@@ -316,8 +322,9 @@ class Job:
         j.out_z = self.out_z.data_ptr() if self.out_z is not None else None
         j.dz_extra = self.dz_extra.data_ptr() if self.dz_extra is not None else None
         self.layout.fill_head(j)
-        if any(o is None for o in self.out_loc[:s.M]):
-            j.reg_head = 0                            # the head reads the exported reconstructions
+        if j.reg_head:
+            self.prepare_regression()
+            j.reg_resid, j.reg_dres = self.reg_resid.data_ptr(), self.reg_dres.data_ptr()
         j.reg_lambda = self.reg_lambda
         j.fi_target = self.fi_target.data_ptr() if self.fi_target is not None else None
         j.out_fi_pred = self.out_fi_pred.data_ptr() if self.out_fi_pred is not None else None
@@ -499,12 +506,19 @@ class JobSet:
         _lib.check(self.lib.nm_head_classifier(ptr, len(self.jobs), int(step), int(tile0), int(n_tiles), int(flags),
                                                _stream_ptr(self.device)), "nm_head_classifier")
 
-    def train_endtoend(self, n_steps: int):
+    def _train_head(self, step0: int, n_steps: int, flags: int = 0):
+        """nm_train_steps_head: all n_steps in one persistent launch, the trunk's forward evaluated once per step."""
+        ptr = self._upload(1)
+        _lib.check(self.lib.nm_train_steps_head(ptr, len(self.jobs), int(step0), int(n_steps), int(flags),
+                                                _stream_ptr(self.device)), "nm_train_steps_head")
+
+    def train_endtoend(self, n_steps: int, fused: bool = True):
         """n_steps train steps of cVAE_multimodal_endtoend jobs on the device, no host sync (the loop of
         multimodal_kfold_cvae_nmpmcont.py:257-303): per step (i) forward with latent and per-subject deviations
         exported, (ii) the classifier head: forward (train-mode BatchNorm / Dropout), cross entropy, contrastive
-        hinge, backward, its Adam update, d CE / d z and the hinge row coefficients, (iii) the trunk's fused
-        forward + weighted ELBO + backward + Adam with those extra gradients."""
+        hinge, backward, its Adam update, d CE / d z and the hinge row coefficients, (iii) the trunk's backward + Adam
+        with those extra gradients.  fused (default): one persistent launch for all steps (nm_train_steps_head);
+        fused=False: the three-launches-per-step form it replaced (trunk forward twice), kept as a cross-check."""
         step0 = self.jobs[0].step
         for j in self.jobs:
             if j.spec.kind != "endtoend" or not j.spec.classifier_layers or j.labels is None:
@@ -516,20 +530,22 @@ class JobSet:
         nb = self.jobs[0].batches_per_epoch
         if any(j.batches_per_epoch != nb for j in self.jobs):
             raise ValueError("jobs of one set must have the same number of batches")
-        for s in range(step0, step0 + n_steps):
-            self._launch(s, 1, 1, _lib.NM_F_EXPORT)
-            self.head_classifier(backward=True, grads=False, adam=True, bn_stats=True, step=s, tile0=s % nb)
-            self._launch(s, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)
+        if fused:
+            self._train_head(step0, n_steps, _lib.NM_F_BNSTATS)
+        else:
+            for s in range(step0, step0 + n_steps):
+                self._launch(s, 1, 1, _lib.NM_F_EXPORT)
+                self.head_classifier(backward=True, grads=False, adam=True, bn_stats=True, step=s, tile0=s % nb)
+                self._launch(s, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)
         for j in self.jobs:
             j.step += n_steps
             j.t += n_steps
 
     def train_regression(self, n_steps: int):
-        """n_steps train steps of cVAE_multimodal_regression jobs, everything on the device, no host sync
-        (the loop of multimodal_kfold_train_cvae_supervised_regression.py:112-125): per step (i) forward with
-        the reconstructions exported, (ii) the regressor: forward, MSE, backward, its Adam update, d MSE / d x_hat,
-        (iii) the trunk's fused forward + ELBO + backward + Adam with that extra gradient.  (i) and (iii) draw the
-        same eps (counter-based generator keyed by the step, or the same block of job.eps)."""
+        """n_steps train steps of cVAE_multimodal_regression jobs in one persistent launch, no host sync (the loop of
+        multimodal_kfold_train_cvae_supervised_regression.py:112-125): per step (i) the trunk's forward, leaving the
+        residuals as bf16 chunk images, (ii) the regressor: forward, MSE, backward, its Adam update, d MSE / d x_hat,
+        (iii) the trunk's backward + Adam with that extra gradient (nm_train_steps_head)."""
         step0 = self.jobs[0].step
         for j in self.jobs:
             if j.spec.kind != "regression" or j.fi_target is None:
@@ -540,13 +556,14 @@ class JobSet:
         nb = self.jobs[0].batches_per_epoch
         if any(j.batches_per_epoch != nb for j in self.jobs):
             raise ValueError("jobs of one set must have the same number of batches")
-        for s in range(step0, step0 + n_steps):
-            self._launch(s, 1, 1, _lib.NM_F_EXPORT)
-            self.head_regression(backward=True, grads=False, adam=True, step=s, tile0=s % nb)
-            self._launch(s, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)
+        self._train_head(step0, n_steps)
         for j in self.jobs:
             j.step += n_steps
             j.t += n_steps
+
+    def grads_head(self, step: int = 0, bn_stats: bool = False):
+        """Gradients of one head-model step's total loss into job.grads, no update (the eager facade's backward)."""
+        self._train_head(step, 1, _lib.NM_F_GRADS | (_lib.NM_F_BNSTATS if bn_stats else 0))
 
     def losses(self) -> torch.Tensor:
         """[n_jobs, loss_cap, 8] on the host."""

@@ -21,6 +21,7 @@ from . import _lib
 
 DM_KINDS = ("dmvae", "weighted_dmvae", "mmvaeplus")
 ALIGN = 4   # floats
+HEAD_CHUNK = 64   # regression head: every modality's residual columns are padded to whole chunks (XCH in nmhip.hip)
 TILE = 16   # weight matrices are stored as TILE x TILE tiles (wt_off() in nmhip.hip)
 REGRESSOR_WIDTHS = (128, 64, 1)   # cVAE.py:2249-2253
 
@@ -196,13 +197,25 @@ class ParamLayout:
         self.offsets: Dict[str, int] = {}          # kernel (tiled) buffer
         self.tiles: Dict[str, Tuple[int, int]] = {}   # weight matrices: (row tiles, column tiles)
         self.nat_offsets: Dict[str, int] = {}      # natural buffer: tensors row-major, back to back
+        # kernel-side column of every reference column, for matrices the kernel keeps with gaps: regressor.0.weight has
+        # each modality's columns padded to whole 64-column chunks (nm_job_t.reg_w, include/nmhip.h)
+        self.colmap: Dict[str, torch.Tensor] = {}
+        self._kcols: Dict[str, int] = {}
+        if spec.kind == "regression":
+            cols, base = [], 0
+            for d in spec.input_dims:
+                cols.append(torch.arange(d) + base)
+                base += (d + HEAD_CHUNK - 1) // HEAD_CHUNK * HEAD_CHUNK
+            self.colmap["regressor.0.weight"] = torch.cat(cols)
+            self._kcols = {"regressor.0.weight": base}
         off = nat = 0
         for name, shape in tensor_table(spec):
             self.names.append(name)
             self.shapes[name] = shape
             if name.endswith(".weight") and len(shape) == 2:
                 off = (off + TILE * TILE - 1) // (TILE * TILE) * (TILE * TILE)
-                nt, kt = (shape[0] + TILE - 1) // TILE, (shape[1] + TILE - 1) // TILE
+                kcols = self._kcols[name] if name in self.colmap else shape[1]
+                nt, kt = (shape[0] + TILE - 1) // TILE, (kcols + TILE - 1) // TILE
                 self.tiles[name] = (nt, kt)
                 n = nt * kt * TILE * TILE
             else:
@@ -231,7 +244,10 @@ class ParamLayout:
         if name in self.tiles:
             n, k = self.shapes[name]
             nt, kt = self.tiles[name]
-            return self._tile_view(flat, name).reshape(nt * TILE, kt * TILE)[:n, :k]
+            full = self._tile_view(flat, name).reshape(nt * TILE, kt * TILE)
+            if name in self.colmap:
+                return full[:n][:, self.colmap[name].to(flat.device)]
+            return full[:n, :k]
         o = self.offsets[name]
         return flat[o:o + self.numel(name)].view(self.shapes[name])
 
@@ -241,7 +257,10 @@ class ParamLayout:
             n, k = self.shapes[name]
             nt, kt = self.tiles[name]
             pad = torch.zeros(nt * TILE, kt * TILE, dtype=torch.float32, device=flat.device)
-            pad[:n, :k] = t
+            if name in self.colmap:
+                pad[:n, self.colmap[name].to(flat.device)] = t
+            else:
+                pad[:n, :k] = t
             self._tile_view(flat, name).copy_(pad.view(nt, TILE, kt, TILE))
         else:
             self.get(flat, name).copy_(t)

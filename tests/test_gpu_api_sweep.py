@@ -352,8 +352,8 @@ def test_endtoend_model_matches_reference():
 
 
 def test_fused_endtoend_training_matches_reference_trajectory():
-    """JobSet.train_endtoend (export launch, classifier-head kernel with its Adam and BatchNorm statistics,
-    trunk launch with d CE / d z and the hinge row coefficients) against the reference class's own 3-step
+    """JobSet.train_endtoend (one persistent launch: trunk forward with exports, classifier head with its Adam and
+    BatchNorm statistics, trunk backward with d CE / d z and the hinge row coefficients) against the reference class's own 3-step
     trajectory (golden e2e3: classifier in train mode, dropout 0, margin 1, w_c 1)."""
     from tests.hip_harness import swap_batch
     g = Golden("e2e3")
@@ -519,7 +519,7 @@ def test_confusion_metrics_kernel_vs_oracle():
 
 
 def test_fused_regression_training_matches_reference_trajectory():
-    """JobSet.train_regression (three launches per step, Adam inside the kernels) against the reference class's
+    """JobSet.train_regression (one persistent launch, Adam inside the kernel) against the reference class's
     own 3-step trajectory (golden reg3_gpoe) and against the eager facade path (same kernels, gradients through
     job.grads + flat Adam)."""
     from tests.hip_harness import make_job, swap_batch
@@ -554,6 +554,35 @@ def test_fused_regression_training_matches_reference_trajectory():
     sd_f, sd_e = job.state_dict(), model.state_dict()
     worst = max(float((sd_f[k] - sd_e[k]).abs().max()) for k in sd_f)
     assert worst <= 2e-6, worst
+
+
+def test_endtoend_one_launch_equals_three_launches_per_step():
+    """nm_train_steps_head (one persistent launch, trunk forward once per step, head between the two decoder passes)
+    against the three-launches-per-step form it replaced (export launch, head kernel, fused trunk launch that runs the
+    forward a second time): 5 steps with the in-kernel generator, dropout on; parameters, loss rows and logits agree to
+    rounding (LDS atomics in the BatchNorm sums; the two trunk instantiations may contract the NLL sum differently)."""
+    # end-to-end model with classifier
+    g = Golden("e2e3")
+    layers = [int(v) for v in g.z["layers"]]
+    spec = nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim, True, "endtoend", tuple(layers), 2)
+    state = {k: v for k, v in g.weights("w0").items() if not k.endswith("num_batches_tracked")}
+    jobs = []
+    for _ in range(2):
+        tables = [nm.Table(g.xs(0)[m], g.t("c")[0], DEV) for m in range(g.M)]
+        job = nm.Job(spec, tables, combine="poe", state=state, kl_weight=0.1, ll_weight=0.1, single_bypass=False)
+        job.cls_margin, job.cls_w_contrast, job.cls_dropout = 1.0, 1.0, 0.25
+        job.set_labels(g.t("labels")[0])
+        jobs.append(job)
+    nm.JobSet([jobs[0]]).train_endtoend(5, fused=True)
+    nm.JobSet([jobs[1]]).train_endtoend(5, fused=False)
+    torch.cuda.synchronize()
+    a, b = jobs[0].state_dict(), jobs[1].state_dict()
+    # (the classifier's BatchNorm column sums are LDS atomics: their order, hence the last bit, may vary from run to run)
+    bad = {k: float((a[k] - b[k]).abs().max()) for k in a if float((a[k] - b[k]).abs().max()) > 1e-6 * float(b[k].abs().max()) + 1e-9}
+    assert not bad, bad
+    la, lb = jobs[0].loss_log.cpu(), jobs[1].loss_log.cpu()
+    assert float((la - lb).abs().max()) <= 2e-7 * float(lb.abs().max()), ((la != lb).nonzero().tolist(), la[la != lb].tolist(), lb[la != lb].tolist())
+    assert float((jobs[0].out_logits - jobs[1].out_logits).abs().max()) <= 1e-5
 
 
 def test_regression_sweep_end_to_end_small():

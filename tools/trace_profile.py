@@ -9,20 +9,54 @@ from multi_modal_normative_modeling_amd import prep, workload, _lib
 TAGS = {0: "enc L0 fwd", 1: "enc hidden fwd", 2: "enc heads", 3: "latent + KL", 4: "zc build", 5: "dec hidden fwd",
         6: "out: wait+x req+mfma", 7: "out: epilogue", 8: "out: dlv + dgrad", 9: "out: wgrad+adam", 10: "dec bwd dgrad+act",
         11: "dec bwd wgrad+adam", 12: "dz + fusion bwd", 13: "enc bwd heads dgrad+act", 14: "enc bwd heads/hidden wgrad+...",
-        15: "enc L0 wgrad+adam", 62: "tail", 63: "step barrier"}
+        15: "enc L0 wgrad+adam", 62: "tail", 63: "step barrier",
+        20: "pass-1 hand-off", 21: "reg head: layer 1 fwd", 22: "reg head: layers 2-3 + MSE", 23: "reg head: bwd layers 3-2",
+        24: "reg head: L1 dgrad + d x_hat", 25: "reg head: L1 wgrad+adam", 26: "cls head: hidden fwd", 27: "cls head: out + CE + hinge",
+        29: "head tail (cls: backward) + hand-off"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--procedure", default="SM-T1w_sMRI")
+ap.add_argument("--head", choices=["", "regression", "endtoend"], default="",
+                help="trace the head-model launch (nm_train_steps_head) of 3 x 379 regression / config-5 end-to-end jobs")
 a = ap.parse_args()
 cohort = prep.synthetic_cohort(n=1280, d=379)
-jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, a.jobs, "cuda:0")
-js = nm.JobSet(jobs)
-js.train(4); torch.cuda.synchronize()
 lib = _lib.load()
 buf = (C.c_ulonglong * 512)()
-lib.nm_trace_read(buf, 1)
-js._launch(js.jobs[0].step, a.steps, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | _lib.NM_F_TRACE)
+if a.head:
+    import numpy as np
+    folds = prep.kfold_indices(len(cohort.iid), 5)
+    tabs, jobs = {}, []
+    for j in range(a.jobs):
+        k = j % 5
+        if a.head == "regression":
+            if k not in tabs:
+                xs, _ = prep.fold_train_tables(cohort, prep.HCP_MODALITIES, folds[k][0])
+                cov = np.stack([cohort.age, cohort.gender], axis=1).astype(np.float32)
+                tabs[k] = [nm.Table(x, cov[folds[k][0]], "cuda:0") for x in xs]
+            job = nm.Job(nm.ModelSpec([379] * 3, [110, 110], 10, 2, True, "regression"), tabs[k], combine="gpoe", seed=j,
+                         init_seed=42 + j, loss_cap=8)
+            job.set_fi(cohort.fi[folds[k][0]].astype(np.float32))
+        else:
+            if k not in tabs:
+                xs, c = prep.fold_train_tables(cohort, prep.HCP_MODALITIES, folds[k][0])
+                tabs[k] = [nm.Table(x, c, "cuda:0") for x in xs]
+            job = nm.Job(nm.ModelSpec([379] * 3, [110, 110], 64, 29, True, "endtoend", (128, 64, 32), 2), tabs[k], combine="poe",
+                         kl_weight=0.1, ll_weight=0.1, seed=j, init_seed=42 + j, loss_cap=8, single_bypass=False)
+            job.cls_dropout = 0.5
+            job.set_labels((cohort.dia != 1).astype(np.int32)[folds[k][0]])
+        jobs.append(job)
+    js = nm.JobSet(jobs)
+    run = js.train_regression if a.head == "regression" else js.train_endtoend
+    run(4); torch.cuda.synchronize()
+    lib.nm_trace_read(buf, 1)
+    js._train_head(js.jobs[0].step, a.steps, _lib.NM_F_TRACE)
+else:
+    jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, a.jobs, "cuda:0")
+    js = nm.JobSet(jobs)
+    js.train(4); torch.cuda.synchronize()
+    lib.nm_trace_read(buf, 1)
+    js._launch(js.jobs[0].step, a.steps, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | _lib.NM_F_TRACE)
 torch.cuda.synchronize()
 lib.nm_trace_read(buf, 1)
 tot = [sum(buf[w * 64 + t] for t in range(64)) / a.steps for w in range(8)]
