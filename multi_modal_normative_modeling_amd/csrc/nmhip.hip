@@ -1693,8 +1693,11 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // the (dead) z|c slot of the workspace, and each encoder's backward below starts from a 16-byte copy of its
   // columns.  Falls back to one evaluation per encoder when the deltas do not fit in 128 columns.
   const bool once = fused && Me >= 2 && Me * 2 * Zs <= PW && !split && S == 0;
+  // Wider latents (config 5: Z = 64, three experts): still ONE evaluation, every expert's [d mu | d logvar] block
+  // written straight to its own (dead) z|c slot of the workspace, [256][PW] like the hand-off above.
+  const bool once_ws = fused && Me >= 2 && !once && 2 * Zs <= PW && !split && S == 0;
   // (split: the alpha sums ride on the part's own evaluation of the fusion backward, below)
-  if (once || (fused && J->combine == NM_COMBINE_GPOE && !split)) {
+  if (once || once_ws || (fused && J->combine == NM_COMBINE_GPOE && !split)) {
     relaunder(c);
     float dal[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
     if (once) {                                    // zero pads of every expert's block: columns [Z, Zs) of both halves
@@ -1704,6 +1707,15 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         const int r = idiv(e, cols, rc_), j = e - r * cols;
         const int blk = idiv(j, npz, 1.0f / (float)npz), k = j - blk * npz;      // blk = 2 m + half
         c.Q[r * LDP + blk * Zs + Z + k] = (__bf16)0.0f;
+      }
+    }
+    if (once_ws && Zs > Z) {                       // the same pads, in the experts' workspace blocks
+      const int npz = Zs - Z, cols = Me * 2 * npz;
+      const float rc_ = 1.0f / (float)cols;
+      for (int e = c.tid; e < ROWS * cols; e += WG) {
+        const int r = idiv(e, cols, rc_), j = e - r * cols;
+        const int blk = idiv(j, npz, 1.0f / (float)npz), k = j - blk * npz;      // blk = 2 m + half
+        ((gbf16)(ws_zc0 + (int64_t)(blk >> 1) * wl.act))[r * PW + (blk & 1) * Zs + Z + k] = (__bf16)0.0f;
       }
     }
     for (int e = c.tid; e < ROWS * Zc; e += WG) {
@@ -1724,6 +1736,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
           c.Q[r * LDP + m * 2 * Zs + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
           c.Q[r * LDP + m * 2 * Zs + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
+        }
+        if (once_ws && m < Me) {
+          if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
+          gbf16 blk = (gbf16)(ws_zc0 + (int64_t)m * wl.act);
+          blk[r * PW + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
+          blk[r * PW + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
         }
       }
     }
@@ -1759,12 +1777,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const GAS char* act_last = ws_enc + (int64_t)(m * L + (L - 1)) * ACT_BYTES;
     dma_lin(c, wsh + md.heads_s, Qb, IMG_BYTES >> 10);
     dma_lin(c, act_last + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
-    if (once) {                                    // this expert's columns of the saved fusion backward
+    if (once || once_ws) {                         // this expert's columns of the saved fusion backward
       const int segs = (2 * Zs) >> 3;              // 16-byte pieces per row
       const float rs_ = 1.0f / (float)segs;
+      gcbf16 src = once ? (gcbf16)(ws_fz + m * 2 * Zs) : (gcbf16)(ws_zc0 + (int64_t)m * wl.act);
       for (int p_ = c.tid; p_ < ROWS * segs; p_ += WG) {
         const int row = idiv(p_, segs, rs_), seg = p_ - row * segs;
-        *reinterpret_cast<u32x4*>(c.P + row * LDP + seg * 8) = *(const GAS u32x4*)(ws_fz + row * PW + m * 2 * Zs + seg * 8);
+        *reinterpret_cast<u32x4*>(c.P + row * LDP + seg * 8) = *(const GAS u32x4*)(src + row * PW + seg * 8);
       }
     } else {
       float dal_s[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
