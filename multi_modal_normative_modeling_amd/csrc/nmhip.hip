@@ -1293,7 +1293,59 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
   float kl_part = 0.f;
   relaunder(c);
-  // shared latent column z = head column S + z
+  // Four latent columns of one row per iteration (16-byte loads of every expert's mu / logvar, 16-byte stores of the
+  // joint statistics; the pad columns [Z, Zs) ride along: zero inputs, results never read).  The element-at-a-time
+  // loop spent its time waiting -- each iteration's loads queue behind the previous iteration's stores.
+  if (S == 0) {
+    const int nq4 = (Z + 3) >> 2;
+    const float rq4 = 1.0f / (float)nq4;
+#pragma unroll 2
+    for (int e = c.tid; e < (MODE == 2 ? 0 : ROWS * nq4); e += WG) {
+      const int r = idiv(e, nq4, rq4), z0 = 4 * (e - r * nq4);
+      f32x4 mu4[NM_MAX_EXP], lv4[NM_MAX_EXP];
+#pragma unroll
+      for (int m = 0; m < NM_MAX_EXP; ++m) {
+        mu4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lv4[m] = mu4[m];
+        if (m < Me) {
+          mu4[m] = *(const GAS f32x4*)(ws_mu_m + ((int64_t)m * ROWS + r) * Zs + z0);
+          lv4[m] = *(const GAS f32x4*)(ws_lv_m + ((int64_t)m * ROWS + r) * Zs + z0);
+        }
+      }
+      float ep[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int zc = min(z0 + i, Z - 1);
+        const float v = J->eps ? asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + zc]
+                               : randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)zc);
+        ep[i] = (z0 + i < Z) ? v : 0.f;
+      }
+      f32x4 omu, olv, oes;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Lat Lt;
+#pragma unroll
+        for (int m = 0; m < NM_MAX_EXP; ++m) { Lt.mu[m] = mu4[m][i]; Lt.lv[m] = lv4[m][i]; }
+        Fuse f = fuse_fwd(J, Lt, al);
+        float es = ep[i] * expf(0.5f * f.lv);
+        if (c.flags & NM_F_ZGIVEN) { f.mu = ep[i]; es = 0.f; }     // decode(z, c, m): the draw buffer holds z itself
+        omu[i] = f.mu; olv[i] = f.lv; oes[i] = es;
+        if (r < c.nrows && z0 + i < Z) {
+          kl_part += -0.5f * (1.0f + f.lv - f.mu * f.mu - expf(f.lv));
+          if (exportf && part == 0) {
+            int64_t gr = (int64_t)(c.row0 + r) * Z + z0 + i;
+            if (J->out_mu) asg(J->out_mu)[gr] = f.mu;
+            if (J->out_logvar) asg(J->out_logvar)[gr] = f.lv;
+            if (J->out_z) asg(J->out_z)[gr] = f.mu + es;
+          }
+        }
+      }
+      *(GAS f32x4*)(ws_mu_j + r * Zs + z0) = omu;
+      *(GAS f32x4*)(ws_lv_j + r * Zs + z0) = olv;
+      *(GAS f32x4*)(ws_es + r * Zs + z0) = oes;
+    }
+  } else {
+  // (private columns: element at a time) shared latent column z = head column S + z
 #pragma unroll 2
   for (int e = c.tid; e < (MODE == 2 ? 0 : ROWS * Zc); e += WG) {
     int r = idiv(e, Zc, rZc), z = e - r * Zc;
@@ -1317,6 +1369,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         if (J->out_z) asg(J->out_z)[gr] = zz;
       }
     }
+  }
   }
   float kl = (MODE == 2) ? 0.f : block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
   handoff_barrier();                                   // mu_j / es are complete for build_zc
@@ -1718,30 +1771,91 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         ((gbf16)(ws_zc0 + (int64_t)(blk >> 1) * wl.act))[r * PW + (blk & 1) * Zs + Z + k] = (__bf16)0.0f;
       }
     }
-    for (int e = c.tid; e < ROWS * Zc; e += WG) {
-      int r = idiv(e, Zc, rZc), z = e - r * Zc;
-      Lat Lt;
-      load_lat(Lt, r, S + z);
-      float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
-      if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
-      float dmu_j = dz + klw * mj;
-      float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
-      FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
-      const bool rv = r < c.nrows;
+    if (S == 0) {
+      // four latent columns of a row per iteration, as in the forward pass
+      const int nq4 = (Z + 3) >> 2;
+      const float rq4 = 1.0f / (float)nq4;
+      for (int e = c.tid; e < ROWS * nq4; e += WG) {
+        const int r = idiv(e, nq4, rq4), z0 = 4 * (e - r * nq4);
+        f32x4 mu4[NM_MAX_EXP], lv4[NM_MAX_EXP];
 #pragma unroll
-      for (int m = 0; m < NM_MAX_EXP; ++m) {
-        dal[m] += rv ? G.dal[m] : 0.f;
-        if (once && m < Me) {
-          // d (tc_weight tc) / d mu_m[r][z] = -(tc_weight / Me) softmax over the rows
-          if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
-          c.Q[r * LDP + m * 2 * Zs + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
-          c.Q[r * LDP + m * 2 * Zs + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
+        for (int m = 0; m < NM_MAX_EXP; ++m) {
+          mu4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          lv4[m] = mu4[m];
+          if (m < Me) {
+            mu4[m] = *(const GAS f32x4*)(ws_mu_m + ((int64_t)m * ROWS + r) * Zs + z0);
+            lv4[m] = *(const GAS f32x4*)(ws_lv_m + ((int64_t)m * ROWS + r) * Zs + z0);
+          }
         }
-        if (once_ws && m < Me) {
-          if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
-          gbf16 blk = (gbf16)(ws_zc0 + (int64_t)m * wl.act);
-          blk[r * PW + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
-          blk[r * PW + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
+        const f32x4 mj4 = *(const GAS f32x4*)(ws_mu_j + r * Zs + z0), lj4 = *(const GAS f32x4*)(ws_lv_j + r * Zs + z0);
+        const f32x4 es4 = *(const GAS f32x4*)(ws_es + r * Zs + z0);
+        f32x4 dz4 = *(const GAS f32x4*)(ws_dz0 + r * Zs + z0);
+        for (int q = 1; q < M; ++q) dz4 += *(const GAS f32x4*)(ws_dz0 + (int64_t)q * ROWS * Zs + r * Zs + z0);
+        if (J->dz_extra) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dz4[i] += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + min(z0 + i, Z - 1)];
+        }
+        bf16x4 pmu[NM_MAX_EXP], plv[NM_MAX_EXP];
+        const bool rv = r < c.nrows;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Lat Lt;
+#pragma unroll
+          for (int m = 0; m < NM_MAX_EXP; ++m) { Lt.mu[m] = mu4[m][i]; Lt.lv[m] = lv4[m][i]; }
+          const float dmu_j = dz4[i] + klw * mj4[i];
+          const float dlv_j = 0.5f * dz4[i] * es4[i] + klw * 0.5f * (expf(lj4[i]) - 1.0f);
+          FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+          const bool ok = rv && z0 + i < Z;
+#pragma unroll
+          for (int m = 0; m < NM_MAX_EXP; ++m) {
+            dal[m] += ok ? G.dal[m] : 0.f;
+            if ((once || once_ws) && m < Me) {
+              // d (tc_weight tc) / d mu_m[r][z] = -(tc_weight / Me) softmax over the rows
+              if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + min(z0 + i, Z - 1)]);
+              pmu[m][i] = (__bf16)(ok ? G.dmu[m] : 0.f);
+              plv[m][i] = (__bf16)(ok ? G.dlv[m] : 0.f);
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < NM_MAX_EXP; ++m) {
+          if (once && m < Me) {
+            *reinterpret_cast<bf16x4*>(c.Q + r * LDP + m * 2 * Zs + z0) = pmu[m];
+            *reinterpret_cast<bf16x4*>(c.Q + r * LDP + m * 2 * Zs + Zs + z0) = plv[m];
+          }
+          if (once_ws && m < Me) {
+            gbf16 blk = (gbf16)(ws_zc0 + (int64_t)m * wl.act);
+            *(GAS bf16x4*)(blk + r * PW + z0) = pmu[m];
+            *(GAS bf16x4*)(blk + r * PW + Zs + z0) = plv[m];
+          }
+        }
+      }
+    } else {
+      for (int e = c.tid; e < ROWS * Zc; e += WG) {
+        int r = idiv(e, Zc, rZc), z = e - r * Zc;
+        Lat Lt;
+        load_lat(Lt, r, S + z);
+        float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
+        if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
+        float dmu_j = dz + klw * mj;
+        float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
+        FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+        const bool rv = r < c.nrows;
+  #pragma unroll
+        for (int m = 0; m < NM_MAX_EXP; ++m) {
+          dal[m] += rv ? G.dal[m] : 0.f;
+          if (once && m < Me) {
+            // d (tc_weight tc) / d mu_m[r][z] = -(tc_weight / Me) softmax over the rows
+            if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
+            c.Q[r * LDP + m * 2 * Zs + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
+            c.Q[r * LDP + m * 2 * Zs + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
+          }
+          if (once_ws && m < Me) {
+            if (tcw != 0.f) G.dmu[m] -= tcw * expf(Lt.mu[m] - c.lse[m * Z + z]);
+            gbf16 blk = (gbf16)(ws_zc0 + (int64_t)m * wl.act);
+            blk[r * PW + z] = (__bf16)(rv ? G.dmu[m] : 0.f);
+            blk[r * PW + Zs + z] = (__bf16)(rv ? G.dlv[m] : 0.f);
+          }
         }
       }
     }
@@ -1801,23 +1915,70 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         c.P[r * LDP + i] = (__bf16)(r < c.nrows ? d : 0.f);
         c.P[r * LDP + Zs + i] = (__bf16)0.0f;
       }
-#pragma unroll 2
-      for (int e = c.tid; e < ROWS * Zc; e += WG) {
-        int r = idiv(e, Zc, rZc), z = e - r * Zc;
-        Lat Lt;
-        load_lat(Lt, r, S + z);
-        float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
-        if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
-        float dmu_j = dz + klw * mj;
-        float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
-        FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
-        const bool rv = r < c.nrows;
-        float dmu_m = pick(G.dmu, m);
-        if (tcw != 0.f) dmu_m -= tcw * expf(pick(Lt.mu, m) - c.lse[m * Z + z]);
-        c.P[r * LDP + S + z] = (__bf16)(rv ? dmu_m : 0.f);
-        c.P[r * LDP + Zs + S + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
+      if (S == 0) {
+        // four latent columns of a row per iteration (as in the forward pass); this expert's deltas only
+        const int nq4 = (Z + 3) >> 2;
+        const float rq4 = 1.0f / (float)nq4;
+        for (int e = c.tid; e < ROWS * nq4; e += WG) {
+          const int r = idiv(e, nq4, rq4), z0 = 4 * (e - r * nq4);
+          f32x4 mu4[NM_MAX_EXP], lv4[NM_MAX_EXP];
 #pragma unroll
-        for (int q = 0; q < NM_MAX_EXP; ++q) dal_s[q] += rv ? G.dal[q] : 0.f;
+          for (int q = 0; q < NM_MAX_EXP; ++q) {
+            mu4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            lv4[q] = mu4[q];
+            if (q < Me) {
+              mu4[q] = *(const GAS f32x4*)(ws_mu_m + ((int64_t)q * ROWS + r) * Zs + z0);
+              lv4[q] = *(const GAS f32x4*)(ws_lv_m + ((int64_t)q * ROWS + r) * Zs + z0);
+            }
+          }
+          const f32x4 mj4 = *(const GAS f32x4*)(ws_mu_j + r * Zs + z0), lj4 = *(const GAS f32x4*)(ws_lv_j + r * Zs + z0);
+          const f32x4 es4 = *(const GAS f32x4*)(ws_es + r * Zs + z0);
+          f32x4 dz4 = *(const GAS f32x4*)(ws_dz0 + r * Zs + z0);
+          for (int q = 1; q < M; ++q) dz4 += *(const GAS f32x4*)(ws_dz0 + (int64_t)q * ROWS * Zs + r * Zs + z0);
+          if (J->dz_extra) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dz4[i] += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + min(z0 + i, Z - 1)];
+          }
+          bf16x4 pmu, plv;
+          const bool rv = r < c.nrows;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            Lat Lt;
+#pragma unroll
+            for (int q = 0; q < NM_MAX_EXP; ++q) { Lt.mu[q] = mu4[q][i]; Lt.lv[q] = lv4[q][i]; }
+            const float dmu_j = dz4[i] + klw * mj4[i];
+            const float dlv_j = 0.5f * dz4[i] * es4[i] + klw * 0.5f * (expf(lj4[i]) - 1.0f);
+            FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+            const bool ok = rv && z0 + i < Z;
+            float dmu_m = pick(G.dmu, m);
+            if (tcw != 0.f) dmu_m -= tcw * expf(pick(Lt.mu, m) - c.lse[m * Z + min(z0 + i, Z - 1)]);
+            pmu[i] = (__bf16)(ok ? dmu_m : 0.f);
+            plv[i] = (__bf16)(ok ? pick(G.dlv, m) : 0.f);
+#pragma unroll
+            for (int q = 0; q < NM_MAX_EXP; ++q) dal_s[q] += ok ? G.dal[q] : 0.f;
+          }
+          *reinterpret_cast<bf16x4*>(c.P + r * LDP + z0) = pmu;
+          *reinterpret_cast<bf16x4*>(c.P + r * LDP + Zs + z0) = plv;
+        }
+      } else {
+#pragma unroll 2
+        for (int e = c.tid; e < ROWS * Zc; e += WG) {
+          int r = idiv(e, Zc, rZc), z = e - r * Zc;
+          Lat Lt;
+          load_lat(Lt, r, S + z);
+          float mj = ws_mu_j[r * Zs + z], lj = ws_lv_j[r * Zs + z], es = ws_es[r * Zs + z], dz = load_dz(r, z);
+          if (J->dz_extra) dz += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + z];
+          float dmu_j = dz + klw * mj;
+          float dlv_j = 0.5f * dz * es + klw * 0.5f * (expf(lj) - 1.0f);
+          FuseGrad G = fuse_bwd(J, Lt, al, dmu_j, dlv_j);
+          const bool rv = r < c.nrows;
+          float dmu_m = pick(G.dmu, m);
+          if (tcw != 0.f) dmu_m -= tcw * expf(pick(Lt.mu, m) - c.lse[m * Z + z]);
+          c.P[r * LDP + S + z] = (__bf16)(rv ? dmu_m : 0.f);
+          c.P[r * LDP + Zs + S + z] = (__bf16)(rv ? pick(G.dlv, m) : 0.f);
+#pragma unroll
+          for (int q = 0; q < NM_MAX_EXP; ++q) dal_s[q] += rv ? G.dal[q] : 0.f;
+        }
       }
       if (split && fused && J->combine == NM_COMBINE_GPOE) {       // this part's alpha: softmax backward of the sums
         float tot[NM_MAX_EXP];
