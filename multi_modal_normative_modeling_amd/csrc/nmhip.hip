@@ -1191,6 +1191,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const int part = split ? c.part : 0;
   const int S = J->n_private, Zc = Z - S;       // DMVAE family: private / shared latent columns (S = 0: all shared)
   const float rZc = Zc > 0 ? 1.0f / (float)Zc : 0.f;
+  // latent phases four columns at a time when the rows divide evenly (measured: with Z = 10 the 12-column groups
+  // leave half the threads a second, mostly padded round -- slower than the element loop; Z = 64: 2.5x faster)
+#ifdef NM_VEC4_ALWAYS
+  const bool vec4 = S == 0;
+#else
+  const bool vec4 = S == 0 && (Z & 3) == 0;
+#endif
   const bool sigm = J->out_kind == 1;           // sigmoid output, ll = -0.5 sum (x - x_hat)^2
   gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m + (int64_t)(step & 1) * M * wl.lat);
   gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m + (int64_t)(step & 1) * M * wl.lat);
@@ -1294,9 +1301,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   float kl_part = 0.f;
   relaunder(c);
   // Four latent columns of one row per iteration (16-byte loads of every expert's mu / logvar, 16-byte stores of the
-  // joint statistics; the pad columns [Z, Zs) ride along: zero inputs, results never read).  The element-at-a-time
+  // joint statistics).  The element-at-a-time
   // loop spent its time waiting -- each iteration's loads queue behind the previous iteration's stores.
-  if (S == 0) {
+  if (vec4) {
     const int nq4 = (Z + 3) >> 2;
     const float rq4 = 1.0f / (float)nq4;
 #pragma unroll 2
@@ -1437,6 +1444,16 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     zero_acc(accg);
     float nll_part = 0.f;
     if (exportf && md.out_rowdev) { for (int r = c.tid; r < ROWS; r += WG) c.rowacc[r] = 0.f; }
+    // per row, the same for every chunk: the hinge's row coefficient (read once), the row's squared deviation (summed in
+    // registers over the chunks, reduced once after the loop)
+    // (two-pass modes only: the one-pass step has no registers to spare for them)
+    constexpr int NRC = MODE == 2 ? RT : 1, NRD = MODE == 1 ? RT : 1;
+    float rcv[NRC], rdev[NRD];
+#pragma unroll
+    for (int rt = 0; rt < NRD; ++rt) rdev[rt] = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRC; ++rt)
+      rcv[rt] = (MODE == 2 && md.dloc_rowcoef) ? asg(md.dloc_rowcoef)[c.row0 + c.wm * WROWS + rt * 16 + c.c16] : 0.f;
     // read once, outside the per-lane selects below: a descriptor load inside `cond ? load * x : 0` becomes a
     // lane-divergent branch, and register spills placed around such branches are not safe with this compiler
     // (tools/check_spill_exec.py)
@@ -1549,8 +1566,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ex[i] += (float)exh[rt][i];
           }
-          float rc = 0.f;
-          if (md.dloc_rowcoef) rc = asg(md.dloc_rowcoef)[c.row0 + r];      // contrastive hinge: rc * (x_hat - x)
+          float rc = rcv[MODE == 2 ? rt : 0];                              // contrastive hinge: rc * (x_hat - x)
+          if (MODE != 2 && md.dloc_rowcoef) rc = asg(md.dloc_rowcoef)[c.row0 + r];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float diff = rv ? acc[rt][i] - xin[rt][i] : 0.f;
@@ -1597,7 +1614,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
                 if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
                 if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
               }
-              if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
+              if (MODE == 1) rdev[MODE == 1 ? rt : 0] += rs;
+              else if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
             }
           }
         }
@@ -1652,6 +1670,15 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_LL_M + m] = ll_this;
     prof(c, PH_NLL_RED);
     if (exportf && md.out_rowdev) {
+      if (MODE == 1) {
+#pragma unroll
+        for (int rt = 0; rt < NRD; ++rt) {          // the row's 4 column groups of this wave, then the 4 waves of the row half
+          float v = rdev[rt];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (c.g == 0) atomicAdd(&c.rowacc[c.wm * WROWS + rt * 16 + c.c16], v);
+        }
+      }
       lds_barrier();
       for (int r = c.tid; r < c.nrows; r += WG) asg(md.out_rowdev)[c.row0 + r] = c.rowacc[r] / (float)D;
     }
@@ -1730,9 +1757,31 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   prof(c, PH_ALPHA);
   // d z = sum over the decoders, in decoder order (single workgroup: accumulated in place in that order)
   // d z of shared column z = sum over the decoders, in decoder order
+  // (every copy is requested before the first is used: a loop over M would wait for each in turn)
   auto load_dz = [&](int r, int z) {
-    float d = ws_dz0[r * Zs + z];
-    for (int q = 1; q < M; ++q) d += ws_dz0[(int64_t)q * ROWS * Zs + r * Zs + z];
+#ifdef NM_DZ_LOOP
+    float d0 = ws_dz0[r * Zs + z];
+    for (int q = 1; q < M; ++q) d0 += ws_dz0[(int64_t)q * ROWS * Zs + r * Zs + z];
+    return d0;
+#endif
+    float dq[NM_MAX_MOD];
+#pragma unroll
+    for (int q = 0; q < NM_MAX_MOD; ++q) dq[q] = (q < M) ? ws_dz0[(int64_t)q * ROWS * Zs + r * Zs + z] : 0.f;
+    float d = dq[0];
+#pragma unroll
+    for (int q = 1; q < NM_MAX_MOD; ++q) d += dq[q];
+    return d;
+  };
+  auto load_dz4 = [&](int r, int z0) {
+    f32x4 dq[NM_MAX_MOD];
+#pragma unroll
+    for (int q = 0; q < NM_MAX_MOD; ++q) {
+      dq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < M) dq[q] = *(const GAS f32x4*)(ws_dz0 + (int64_t)q * ROWS * Zs + r * Zs + z0);
+    }
+    f32x4 d = dq[0];
+#pragma unroll
+    for (int q = 1; q < NM_MAX_MOD; ++q) d += dq[q];
     return d;
   };
 
@@ -1771,7 +1820,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         ((gbf16)(ws_zc0 + (int64_t)(blk >> 1) * wl.act))[r * PW + (blk & 1) * Zs + Z + k] = (__bf16)0.0f;
       }
     }
-    if (S == 0) {
+    if (vec4) {
       // four latent columns of a row per iteration, as in the forward pass
       const int nq4 = (Z + 3) >> 2;
       const float rq4 = 1.0f / (float)nq4;
@@ -1789,8 +1838,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         }
         const f32x4 mj4 = *(const GAS f32x4*)(ws_mu_j + r * Zs + z0), lj4 = *(const GAS f32x4*)(ws_lv_j + r * Zs + z0);
         const f32x4 es4 = *(const GAS f32x4*)(ws_es + r * Zs + z0);
-        f32x4 dz4 = *(const GAS f32x4*)(ws_dz0 + r * Zs + z0);
-        for (int q = 1; q < M; ++q) dz4 += *(const GAS f32x4*)(ws_dz0 + (int64_t)q * ROWS * Zs + r * Zs + z0);
+        f32x4 dz4 = load_dz4(r, z0);
         if (J->dz_extra) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) dz4[i] += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + min(z0 + i, Z - 1)];
@@ -1915,7 +1963,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         c.P[r * LDP + i] = (__bf16)(r < c.nrows ? d : 0.f);
         c.P[r * LDP + Zs + i] = (__bf16)0.0f;
       }
-      if (S == 0) {
+      if (vec4) {
         // four latent columns of a row per iteration (as in the forward pass); this expert's deltas only
         const int nq4 = (Z + 3) >> 2;
         const float rq4 = 1.0f / (float)nq4;
@@ -1933,8 +1981,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           }
           const f32x4 mj4 = *(const GAS f32x4*)(ws_mu_j + r * Zs + z0), lj4 = *(const GAS f32x4*)(ws_lv_j + r * Zs + z0);
           const f32x4 es4 = *(const GAS f32x4*)(ws_es + r * Zs + z0);
-          f32x4 dz4 = *(const GAS f32x4*)(ws_dz0 + r * Zs + z0);
-          for (int q = 1; q < M; ++q) dz4 += *(const GAS f32x4*)(ws_dz0 + (int64_t)q * ROWS * Zs + r * Zs + z0);
+          f32x4 dz4 = load_dz4(r, z0);
           if (J->dz_extra) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dz4[i] += asg(J->dz_extra)[(int64_t)(c.row0 + r) * Z + min(z0 + i, Z - 1)];
