@@ -408,7 +408,9 @@ __device__ __forceinline__ void wait_vm(int n) {
   else if (n <= 9) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n <= 11) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if (n <= 13) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (n <= 15) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (n <= 19) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
 }
 // Barrier for hand-offs that go through GLOBAL memory between threads of the workgroup (latent statistics, d z):
 // every wave first drains its own stores, then the workgroup meets.  (One CU's vector L1 is in order for its own
@@ -1176,13 +1178,15 @@ __device__ __forceinline__ float pick(const float (&a)[NM_MAX_EXP], int m) {
 // head: MODE 1 = encoders, fusion and every decoder forward (exports on; all activations incl. every decoder's last
 // hidden one saved), MODE 2 = the decoders' output chunks again from the saved activation -- now with the head's extra
 // gradients -- and the whole backward; no second encoder / fusion / hidden-decoder forward.
+// MODE 3: forward only (deviation pass, predictions): the one-pass step with the backward compiled out.
 template <bool SCALAR_TR, int MODE = 0>
 __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const nm_job_t* J = c.job;
   const int M = J->M, L = J->L, Z = J->Z, C = J->C;
   const int Me = experts(J);                    // modalities that have an encoder
   const bool nl = J->non_linear != 0;
-  const bool bwd = MODE != 1 && (c.flags & NM_F_BACKWARD) != 0;
+  const bool bwd = MODE != 1 && MODE != 3 && (c.flags & NM_F_BACKWARD) != 0;
+  constexpr bool FWD_ONLY = MODE == 1 || MODE == 3;   // output chunks export only: see the chunk loop
   const bool save = bwd || MODE == 1;           // activations go to the workspace
   const bool exportf = MODE != 2 && (c.flags & NM_F_EXPORT) != 0;
   const WsLayout wl = ws_layout(M, L, Z);
@@ -1447,7 +1451,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     // per row, the same for every chunk: the hinge's row coefficient (read once), the row's squared deviation (summed in
     // registers over the chunks, reduced once after the loop)
     // (two-pass modes only: the one-pass step has no registers to spare for them)
-    constexpr int NRC = MODE == 2 ? RT : 1, NRD = MODE == 1 ? RT : 1;
+    constexpr int NRC = MODE == 2 ? RT : 1, NRD = FWD_ONLY ? RT : 1;
     float rcv[NRC], rdev[NRD];
 #pragma unroll
     for (int rt = 0; rt < NRD; ++rt) rdev[rt] = 0.f;
@@ -1466,7 +1470,18 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         ? (GAS char*)asg(J->reg_resid) + ((int64_t)(c.row0 / ROWS) * hq_all + hq_m) * XIMG_BYTES : (GAS char*)nullptr;
     const GAS char* const dres_in = (MODE == 2 && hq_all > 0 && J->reg_dres)    // (one set: the batch in flight)
         ? (const GAS char*)asg(J->reg_dres) + hq_m * XIMG_BYTES : (const GAS char*)nullptr;
-    for (int ch = 0; ch < nck; ++ch) {
+    int young_prev = RT;                          // this wave's vector-memory operations younger than the next blob request
+    // fp32 inputs of chunk `chx` for this lane: 4 consecutive ROI of RT rows
+    auto load_xin = [&](int chx, f32x4 (&xv)[RT]) {
+      const int dcl = min(chx * OCH + c.wn * 16 + 4 * c.g, xp - 4);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        xv[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
+    };
+    // One output chunk.  xin: this chunk's fp32 inputs -- requested here, in flight during the MFMAs (training), or
+    // already requested by the previous chunk (forward only: the chunk is too short to hide them, so chunk ch + 1's are
+    // requested as soon as chunk ch's have arrived, into the other register set `xnx`).
+    auto chunk = [&](const int ch, f32x4 (&xin)[RT], f32x4 (&xnx)[RT]) {
       relaunder(c);
       const int d0 = ch * OCH;
       const int valid = min(OCH, D - d0);
@@ -1484,20 +1499,17 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       PMV pm_a, pm_b;
       if (c.tid < OCH) c.colacc[c.tid] = 0.f;
       // chunk ch's blob (requested a chunk ago) and everything older; from the second chunk on at least the RT
-      // fp32 input loads of the previous chunk are younger than it and may stay in flight (with Adam: its last stores)
-      wait_vm(ch > 0 ? RT : 0);
+      // fp32 input loads of the previous chunk are younger than it and may stay in flight (with Adam: its last stores;
+      // forward only: also the previous chunk's export stores -- waiting for THEIR acknowledgements was most of a
+      // forward-only chunk)
+      wait_vm(ch > 0 ? young_prev : 0);
       lds_barrier();                              // ... for every wave; also: the previous chunk is finished everywhere
-      if (ch + 1 < nck) dma_lin(c, oblob + (int64_t)(ch + 1) * OBLOB_BYTES, other, OBLOB_BYTES >> 10);
+      int n_blob = 0;
+      if (ch + 1 < nck) n_blob = dma_lin(c, oblob + (int64_t)(ch + 1) * OBLOB_BYTES, other, OBLOB_BYTES >> 10);
       // fp32 inputs of the residual (rows are always inside the zero-padded table): in flight during the MFMAs
       const int dl0 = c.wn * 16 + 4 * c.g;        // first of the lane's 4 columns inside the chunk
       const int dg0 = d0 + dl0;
-      f32x4 xin[RT];
-      {
-        const int dcl = min(dg0, xp - 4);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          xin[rt] = *(const GAS f32x4*)(xf + (int64_t)(c.row0 + c.wm * WROWS + rt * 16 + c.c16) * xp + dcl);
-      }
+      if (!FWD_ONLY) load_xin(ch, xin);
       bf16x4 exh[RT];                               // the head's gradient on this lane's 4 x RT outputs (second pass only)
       if (MODE == 2 && dres_in) {
 #pragma unroll
@@ -1526,6 +1538,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         }
       }
       tr(c, 6);
+      if (FWD_ONLY) {
+        // this chunk's inputs have been in flight since the previous chunk's epilogue: make sure of them, then
+        // request the next chunk's
+        // (younger than them and free to stay in flight: the previous chunk's export stores, the blob just requested)
+        wait_vm(ch > 0 ? young_prev - RT + n_blob : 0);
+        if (ch + 1 < nck) load_xin(ch + 1, xnx);
+      }
       // epilogue: residual, NLL, d logvar_out, delta chunk -> Dq.  Lane: 4 consecutive ROI of one row.
       {
         const f32x4 bo = *reinterpret_cast<const f32x4*>(vb + dl0);
@@ -1591,34 +1610,44 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
           nll_part += dv ? hq + (sigm ? 0.f : (float)nvalid * (0.5f * sv[i] + LOG_SQRT_2PI)) : 0.f;
           colsum[i] = dv ? 0.5f * (float)nvalid - hq : 0.f;
         }
-        if (exportf && dg0 < xp) {           // exports share the fp32 table's row pitch: one 16-byte store each
+        // exports share the fp32 table's row pitch: one 16-byte store each.  Forward only: stored for every row of the
+        // tile (zeros on the rows past the table's end -- the buffers hold whole tiles) under a wave-uniform column
+        // test, so that the number of stores a wave issues is known to the next chunk's wait.
+        const bool wave_cols = d0 + c.wn * 16 < xp;
+        if (exportf && (FWD_ONLY ? wave_cols : dg0 < xp)) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const int r = c.wm * WROWS + rt * 16 + c.c16;
-            if (r < c.nrows) {
+            const bool rv = r < c.nrows;
+            if (FWD_ONLY || rv) {
               f32x4 lo, sq;
               float rs = 0.f;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                const bool dv = dg0 + i < D;
+                const bool dv = dg0 + i < D && rv;
                 const float xh = acc[rt][i], diff = xh - xin[rt][i];
                 lo[i] = dv ? xh : 0.f;
                 sq[i] = dv ? diff * diff : 0.f;
                 rs += sq[i];
               }
               const int64_t gi = (int64_t)(c.row0 + r) * xp + dg0;
-              if (MODE == 1) {                    // read back by the head phase of this workgroup
-                if (md.out_loc) *(GAS f32x4*)(asg(md.out_loc) + gi) = lo;
-                if (md.out_sqerr) *(GAS f32x4*)(asg(md.out_sqerr) + gi) = sq;
-              } else {
-                if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
-                if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
+              if (!FWD_ONLY || dg0 < xp) {
+                if (MODE == 1) {                  // read back by the head phase of this workgroup
+                  if (md.out_loc) *(GAS f32x4*)(asg(md.out_loc) + gi) = lo;
+                  if (md.out_sqerr) *(GAS f32x4*)(asg(md.out_sqerr) + gi) = sq;
+                } else {
+                  if (md.out_loc) __builtin_nontemporal_store(lo, (GAS f32x4*)(asg(md.out_loc) + gi));       // written once,
+                  if (md.out_sqerr) __builtin_nontemporal_store(sq, (GAS f32x4*)(asg(md.out_sqerr) + gi));   // read elsewhere
+                }
               }
-              if (MODE == 1) rdev[MODE == 1 ? rt : 0] += rs;
+              if (FWD_ONLY) rdev[FWD_ONLY ? rt : 0] += rs;
               else if (md.out_rowdev) atomicAdd(&c.rowacc[r], rs);
             }
           }
         }
+        if (FWD_ONLY)
+          young_prev = RT + (res_out ? RT : 0) +
+                       ((exportf && wave_cols) ? RT * ((md.out_loc ? 1 : 0) + (md.out_sqerr ? 1 : 0)) : 0);
         if (bwd) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -1633,7 +1662,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       }
       prof(c, PH_X_EPI);
       tr(c, 7);
-      if (!bwd) continue;                         // forward only: the next chunk's barrier protects the slots
+      if (!bwd) return;                           // forward only: the next chunk's barrier protects the slots
       lds_barrier();                              // delta chunk and column sums complete
       relaunder(c);
 #if NM_PRE_OUT == 1
@@ -1658,6 +1687,18 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 #endif
       tr(c, 9);
       prof(c, PH_OUT_WGRAD);
+    };
+    if (FWD_ONLY) {
+      // two register sets that swap roles from chunk to chunk (unrolled by two so that the sets keep their names)
+      f32x4 xa[RT], xb[RT];
+      load_xin(0, xa);
+      for (int ch = 0; ch < nck; ch += 2) {
+        chunk(ch, xa, xb);
+        if (ch + 1 < nck) chunk(ch + 1, xb, xa);
+      }
+    } else {
+      f32x4 xa[RT];
+      for (int ch = 0; ch < nck; ++ch) chunk(ch, xa, xa);
     }
     float nll = block_sum(c, nll_part);
     float ll_this = -nll * c.inv_b;                 // compute_ll: sum over ROI, mean over rows
@@ -1670,7 +1711,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + NM_LOSS_LL_M + m] = ll_this;
     prof(c, PH_NLL_RED);
     if (exportf && md.out_rowdev) {
-      if (MODE == 1) {
+      if (FWD_ONLY) {
 #pragma unroll
         for (int rt = 0; rt < NRD; ++rt) {          // the row's 4 column groups of this wave, then the 4 waves of the row half
           float v = rdev[rt];
@@ -2149,7 +2190,7 @@ __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
   c.tlast = reinterpret_cast<unsigned long long*>(c.lse + 256);
 }
 
-template <bool SCALAR_TR>
+template <bool SCALAR_TR, int MODE = 0>
 __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict__ jobs, int step0, int steps_per_tile,
                                                      int flags, int n_jobs, int nparts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2201,7 +2242,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     if (flags & 64) c.tlast[threadIdx.x >> 6] = clock64();
     lds_barrier();
     relaunder(c);
-    run_step<SCALAR_TR>(c, s);
+    run_step<SCALAR_TR, MODE>(c, s);
     tr(c, 62);
     // the next step reads what this one stored (weights, shadow images, workspace): drain, then meet
     handoff_barrier();
@@ -3232,7 +3273,11 @@ static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int step
     hipLaunchKernelGGL(sync_reset_kernel, dim3((n_jobs * (WS_SYNC_BYTES / 4) + 255) / 256), dim3(256), 0, st, jobs_dev, n_jobs);
   }
   hipError_t e;
-  if (scalar_tr) {
+  if (!scalar_tr && !(flags & NM_F_BACKWARD)) {           // forward only: the instantiation without the backward pass
+    e = hipFuncSetAttribute((const void*)nm_step_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((nm_step_kernel<false, 3>), grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags, n_jobs, parts);
+  } else if (scalar_tr) {
     e = hipFuncSetAttribute((const void*)nm_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(nm_step_kernel<true>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags, n_jobs, parts);

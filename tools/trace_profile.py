@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--procedure", default="SM-T1w_sMRI")
+ap.add_argument("--forward", action="store_true", help="trace the forward-only export launch over all row tiles (deviation pass)")
 ap.add_argument("--head", choices=["", "regression", "endtoend"], default="",
                 help="trace the head-model launch (nm_train_steps_head) of 3 x 379 regression / config-5 end-to-end jobs")
 a = ap.parse_args()
@@ -55,8 +56,18 @@ else:
     jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, a.jobs, "cuda:0")
     js = nm.JobSet(jobs)
     js.train(4); torch.cuda.synchronize()
-    lib.nm_trace_read(buf, 1)
-    js._launch(js.jobs[0].step, a.steps, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | _lib.NM_F_TRACE)
+    if a.forward:
+        for j in jobs:
+            j.enable_exports(loc=False, sqerr=True, rowdev=True, latent=False)
+        nt = jobs[0].tables[0].n_tiles
+        js.forward(); torch.cuda.synchronize()
+        lib.nm_trace_read(buf, 1)
+        a.steps = 4
+        for _ in range(a.steps):
+            js._launch(0, 1, nt, _lib.NM_F_EXPORT | _lib.NM_F_TRACE)
+    else:
+        lib.nm_trace_read(buf, 1)
+        js._launch(js.jobs[0].step, a.steps, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | _lib.NM_F_TRACE)
 torch.cuda.synchronize()
 lib.nm_trace_read(buf, 1)
 tot = [sum(buf[w * 64 + t] for t in range(64)) / a.steps for w in range(8)]
