@@ -323,6 +323,15 @@ __device__ __forceinline__ float randn_ctr(uint64_t seed, uint32_t step, uint32_
   // a parity quantity -- parity runs inject eps
   return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
+// two draws from one hash (both branches of the Box-Muller pair): the 16-byte latent path, keyed by the column pair
+__device__ __forceinline__ void randn2_ctr(uint64_t seed, uint32_t step, uint32_t row, uint32_t zpair, float& n0, float& n1) {
+  const uint64_t h = splitmix64(seed ^ 0x2D0B1E5Dull ^ ((uint64_t)step << 32) ^ ((uint64_t)row << 8) ^ zpair);
+  const float u1 = ((uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1]
+  const float u2 = (uint32_t)(h & 0xFFFFFFu) * (1.0f / 16777216.0f);      // [0, 1)
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
+}
 
 // ---- Adam (torch.optim.Adam as configured at cVAE.py:1111-1116) -------------------------------
 struct AdamK { float b1, b2, eps, step_size, inv_bc2_sqrt; };
@@ -1324,13 +1333,15 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         }
       }
       float ep[4];
+      if (J->eps) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int zc = min(z0 + i, Z - 1);
-        const float v = J->eps ? asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + zc]
-                               : randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)zc);
-        ep[i] = (z0 + i < Z) ? v : 0.f;
+        for (int i = 0; i < 4; ++i) ep[i] = asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + min(z0 + i, Z - 1)];
+      } else {
+        randn2_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)(z0 >> 1), ep[0], ep[1]);
+        randn2_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)(z0 >> 1) + 1u, ep[2], ep[3]);
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ep[i] = (z0 + i < Z) ? ep[i] : 0.f;
       f32x4 omu, olv, oes;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -2501,9 +2512,14 @@ __device__ __forceinline__ void col_reduce(const Ctx& c, const float (&v)[2][4],
       if (c.c16 == 0 && f < N) atomicAdd(&dst[f], s);
     }
 }
-__device__ __forceinline__ float uniform_ctr(uint64_t seed, uint32_t step, uint32_t layer, uint32_t row, uint32_t f) {
-  uint64_t h = splitmix64(seed ^ 0xC1A551F1E5ull ^ ((uint64_t)step << 32) ^ ((uint64_t)layer << 28) ^ ((uint64_t)row << 8) ^ f);
-  return (uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+// Dropout draws: one 64-bit hash per (step, layer, row, group of 4 features) gives the group's four uniforms (16 bits
+// each) -- the hash was most of the classifier's forward time when every element had its own.
+__device__ __forceinline__ f32x4 uniform4_ctr(uint64_t seed, uint32_t step, uint32_t layer, uint32_t row, uint32_t fgroup) {
+  const uint64_t h = splitmix64(seed ^ 0xC1A551F1E5ull ^ ((uint64_t)step << 32) ^ ((uint64_t)layer << 28) ^ ((uint64_t)row << 8) ^ fgroup);
+  f32x4 u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (float)(uint32_t)((h >> (16 * i)) & 0xFFFFu) * (1.0f / 65536.0f);
+  return u;
 }
 
 // (same contract as reg_head_body; `bn_stats`: update the BatchNorm running statistics)
@@ -2621,13 +2637,13 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
         const int r = c.wm * WROWS + rt * 16 + c.c16;
         f32x4 xh;
         bf16x4 pk;
+        f32x4 u4 = {1.f, 1.f, 1.f, 1.f};
+        if (train && J->cls_dropout > 0.f) u4 = uniform4_ctr(J->seed, (uint32_t)step, (uint32_t)li, (uint32_t)(c.row0 + r), (uint32_t)(f0 >> 2));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           xh[i] = (acc[t][rt][i] - mean[t][i]) * rstd[t][i];
           float h = fmaxf(gam[t][i] * xh[i] + bet[t][i], 0.f);
-          if (train && J->cls_dropout > 0.f)
-            h = uniform_ctr(J->seed, (uint32_t)step, (uint32_t)li, (uint32_t)(c.row0 + r), (uint32_t)(f0 + i)) >= J->cls_dropout
-                    ? h * keep_scale : 0.f;
+          if (train && J->cls_dropout > 0.f) h = u4[i] >= J->cls_dropout ? h * keep_scale : 0.f;
           pk[i] = (__bf16)((f0 + i < N && r < c.nrows) ? h : 0.f);
         }
         if (bwd) *(GAS f32x4*)(W.xhat[li] + r * PW + f0) = xh;

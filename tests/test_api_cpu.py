@@ -36,3 +36,37 @@ def test_errors_match_reference_conventions():
             m.forward_multimodal([torch.zeros(2, 5), torch.zeros(2, 6)], [torch.zeros(2, 2)] * 2, "poe")
     with pytest.raises(ValueError):
         nm.cVAE_multimodal([5, 6], [8], 3, 2, modalities=3)
+
+
+def test_regression_head_first_layer_is_stored_chunk_padded():
+    """regressor.0.weight [128][sum D] lives in the kernel buffer as [128][Kh] with every modality's columns padded to
+    whole 64-column chunks (include/nmhip.h, nm_job_t.reg_w): ParamLayout maps both ways, the pad columns are zero, and
+    the natural <-> kernel permutation the eager facade uses agrees with get / put."""
+    from multi_modal_normative_modeling_amd.layout import ModelSpec, ParamLayout
+    dims = [150, 90, 131]
+    lay = ParamLayout(ModelSpec(dims, [48, 32], 10, 2, True, "regression"))
+    name = "regressor.0.weight"
+    assert lay.shapes[name] == (128, sum(dims))
+    assert lay.tiles[name] == (8, (192 + 128 + 192) // 16)                       # Kh = 3 + 2 + 3 chunks of 64
+    g = torch.Generator().manual_seed(0)
+    state = {n: torch.randn(*lay.shapes[n], generator=g) for n in lay.names}
+    flat = lay.flatten(state)
+    back = lay.unflatten(flat)
+    assert all(torch.equal(back[n], state[n]) for n in lay.names)
+    # the padded matrix: modality m at columns [64 q_m, 64 q_m + D_m), zeros elsewhere
+    nt, kt = lay.tiles[name]
+    full = lay._tile_view(flat, name).reshape(nt * 16, kt * 16)
+    w = state[name]
+    assert torch.equal(full[:128, 0:150], w[:, 0:150]) and torch.equal(full[:128, 192:282], w[:, 150:240])
+    assert torch.equal(full[:128, 320:451], w[:, 240:371])
+    mask = torch.ones(kt * 16, dtype=torch.bool)
+    mask[lay.colmap[name]] = False
+    assert float(full[:, mask].abs().max()) == 0.0
+    # natural buffer <-> kernel buffer
+    nat = lay.nat_flatten(state)
+    out = torch.empty(lay.total)
+    lay.nat_to_kernel(nat, out)
+    assert torch.equal(out, flat)
+    nat2 = torch.zeros_like(nat)
+    lay.kernel_to_nat(flat, nat2)
+    assert torch.equal(nat2, nat)
