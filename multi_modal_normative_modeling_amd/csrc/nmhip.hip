@@ -2229,11 +2229,14 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   // zero LDS once: padded columns are multiplied by zero weights and must stay finite
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
-  // De-phase the workgroups of a long launch: identical models otherwise run their HBM-heavy weight-gradient /
-  // Adam phases in lockstep and share the DRAM 256 ways at once (the sleep itself costs up to 7/8 of one step per
-  // launch, hence only for launches of 64 steps or more).
-  if (steps_per_tile >= 64)
-    for (int i = 0; i < J->dephase; ++i) __builtin_amdgcn_s_sleep(127);
+  // De-phase the workgroups of a launch: identical models otherwise run their HBM-heavy weight-gradient / Adam phases
+  // in lockstep and share the DRAM 256 ways at once.  The sleep itself costs up to 7/8 of one step per launch; short
+  // launches (the 20-step form: measured +3..5 % with offsets, profiles/r02_ab_dephase20.txt) get half the spread,
+  // very short ones none.
+  {
+    const int sleeps = steps_per_tile >= 64 ? J->dephase : (steps_per_tile >= 8 ? (J->dephase >> 1) : 0);
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
   const int s_begin = step0 + tile_idx * steps_per_tile;
   for (int s = s_begin; s < s_begin + steps_per_tile; ++s) {

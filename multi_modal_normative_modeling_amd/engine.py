@@ -409,7 +409,7 @@ class JobSet:
             else:
                 per_xcd = max(1, (n + 7) // 8)
                 frac = ((b >> 3) + (b & 7) / 8) / per_xcd
-            s = int(round(step_sleeps * frac))
+            s = int(round(step_sleeps * frac * float(os.environ.get("NMHIP_DEPHASE_SCALE", "1"))))
             if s != j.dephase_sleeps:
                 j.dephase_sleeps = s
                 j._version += 1

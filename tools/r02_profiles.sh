@@ -12,3 +12,6 @@ bash tools/run_pmc_sq.sh $TAG > $O/pmc_sq.txt 2>&1; tail -22 $O/pmc_sq.txt
 python tools/bench_configs.py 2>&1 | grep -v amdgpu > $O/all_configs_256_jobs.txt; cat $O/all_configs_256_jobs.txt
 python tools/trace_profile.py --jobs 256 --procedure SE-gPoE 2>/dev/null > $O/wave_trace_256_jobs_SE.txt
 python tools/trace_profile.py --jobs 1 --procedure SE-gPoE 2>/dev/null > $O/wave_trace_single_job_SE.txt
+python tools/trace_profile.py --jobs 256 --head regression --steps 8 2>/dev/null > $O/wave_trace_256_jobs_regression_head.txt
+python tools/trace_profile.py --jobs 256 --head endtoend --steps 8 2>/dev/null > $O/wave_trace_256_jobs_endtoend_head.txt
+python tools/trace_profile.py --jobs 256 --procedure SM-T1w_sMRI --forward 2>/dev/null > $O/wave_trace_256_jobs_forward_only.txt
