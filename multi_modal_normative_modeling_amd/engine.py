@@ -398,7 +398,12 @@ class JobSet:
         evenly over one step, and the XCDs are staggered against each other by a fraction of that spacing.
         NMHIP_DEPHASE = 0 switches it off, "xcd" is the round-1 scheme (one offset per XCD)."""
         mode = os.environ.get("NMHIP_DEPHASE", "cu")
+        scale = float(os.environ.get("NMHIP_DEPHASE_SCALE", "1"))
         n = len(self.jobs)
+        key = (mode, scale, n)
+        if getattr(self, "_dephase_key", None) == key:          # (host time of a launch matters: it precedes the launch)
+            return
+        self._dephase_key = key
         for b, j in enumerate(self.jobs):
             # ~4.8 shader cycles per parameter and step with the chip full (measured, 118 k .. 642 k parameters)
             step_sleeps = j.layout.n_params * 4.8 / 8128
@@ -409,7 +414,7 @@ class JobSet:
             else:
                 per_xcd = max(1, (n + 7) // 8)
                 frac = ((b >> 3) + (b & 7) / 8) / per_xcd
-            s = int(round(step_sleeps * frac * float(os.environ.get("NMHIP_DEPHASE_SCALE", "1"))))
+            s = int(round(step_sleeps * frac * scale))
             if s != j.dephase_sleeps:
                 j.dephase_sleeps = s
                 j._version += 1
@@ -446,7 +451,9 @@ class JobSet:
         mode = os.environ.get("NMHIP_SPLIT", "auto")
         if mode == "0" or M < 2 or any(len(j.kmods) != M for j in self.jobs):
             return 1
-        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if not hasattr(self, "_cus"):
+            self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        cus = self._cus
         fits = (len(self.jobs) + 7) // 8 * 8 * M <= cus
         return M if fits else 1
 
