@@ -127,9 +127,9 @@ typedef struct nm_job {
                              logsumexp_rows(mu_m[:, z]) (its joint-posterior half is identically zero there); 0 = none   */
   int64_t w_off;          /* WeightedDMVAE.weights [M] in params (cVAE.py:1650): kl_i and ll_i are multiplied by weights[i]
                              and the weights are learned; -1: none                                                    */
-  int32_t dephase;        /* launches of >= 64 steps: the job's workgroup first sleeps dephase * 8128 cycles, so that
-                             identical models do not run their HBM-heavy phases in lockstep (0 = off; the host spreads
-                             the jobs of a launch over one step's worth of cycles, engine.py)                        */
+  int32_t dephase;        /* start offset of the job's workgroup in microseconds (launches of >= 64 steps: all of it, >= 8 steps:
+                             a quarter, shorter: none), so that identical models do not run their HBM-heavy phases in
+                             lockstep (0 = off; the host spreads the jobs of a launch over one step's time, engine.py) */
   int32_t shared_cov;     /* 1: every modality's table carries the same covariate block: the decoder input
                              z | c | 1 is built once per step and reused by the other decoders            */
   int32_t loss_cap;       /* rows of loss_log; step s writes row s % loss_cap            */
@@ -345,6 +345,9 @@ int nm_prof_read(unsigned long long* out32, int reset);
 
 /* NM_F_TRACE read-out: [8 waves][64 tags] interval cycles of workgroup (0,0); reset != 0 clears them. */
 int nm_trace_read(unsigned long long* out512, int reset);
+/* Start / end of the first 512 workgroups of the last NM_F_TRACE launch of the step kernel, [workgroup][start, end] on the
+ * 100 MHz constant-rate counter (diagnostic: how far apart the workgroups of a launch finish). */
+int nm_wgtimes_read(unsigned long long* out1024);
 
 const char* nm_status_string(int status);
 int nm_version(void);

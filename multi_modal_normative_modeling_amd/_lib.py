@@ -139,6 +139,7 @@ def load():
     lib.nm_test_gemm.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     lib.nm_prof_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
     lib.nm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), i32]
+    lib.nm_wgtimes_read.argtypes = [C.POINTER(C.c_ulonglong)]
     sj, sm = i64(0), i64(0)
     lib.nm_abi_sizes(C.byref(sj), C.byref(sm))
     if sj.value != C.sizeof(NmJob) or sm.value != C.sizeof(NmModality):
@@ -151,7 +152,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
-    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
+    "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_wgtimes_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
     "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
 ]

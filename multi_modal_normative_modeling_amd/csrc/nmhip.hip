@@ -78,6 +78,9 @@ __device__ unsigned long long nm_prof_cycles[32];
 // Per-wave interval timers (NM_F_TRACE): cycles between consecutive stamps of each wave of workgroup (0,0),
 // attributed to the tag of the later stamp.
 __device__ unsigned long long nm_trace_cycles[8][64];
+// Start / end of every workgroup of the last NM_F_TRACE launch of nm_step_kernel on the constant-rate (100 MHz) counter
+// that all XCDs share: [workgroup][0 = start, 1 = end], first 512 workgroups.
+__device__ unsigned long long nm_wg_times[512][2];
 
 struct Ctx {
   unsigned long long t_last;
@@ -2206,6 +2209,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
                                                      int flags, int n_jobs, int nparts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int job_idx = blockIdx.x, part = -1;
+  if ((flags & 64) && blockIdx.y == 0 && blockIdx.x < 512 && threadIdx.x == 0) nm_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
   if (flags & NM_F_SPLIT) {
     // workgroups b and b + 8 share an XCD (observed placement; speed only): the parts of a job are consecutive
     // workgroups of ONE XCD, so that their hand-offs and shared expert statistics stay inside one L2
@@ -2230,12 +2234,16 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   // De-phase the workgroups of a launch: identical models otherwise run their HBM-heavy weight-gradient / Adam phases
-  // in lockstep and share the DRAM 256 ways at once.  The sleep itself costs up to 7/8 of one step per launch; short
-  // launches (the 20-step form: measured +3..5 % with offsets, profiles/r02_ab_dephase20.txt) get half the spread,
-  // very short ones none.
+  // in lockstep and share the DRAM 256 ways at once.  nm_job_t.dephase = this job's start offset in microseconds,
+  // waited for on the constant-rate counter (s_sleep counts are not shader cycles: the first version of this, a fixed
+  // number of s_sleep(127), spread the workgroups over three steps instead of one -- tools/wg_spread.py).  The offset
+  // is pure cost at the end of the launch, so short launches get less of it and very short ones none.
   {
-    const int sleeps = steps_per_tile >= 64 ? J->dephase : (steps_per_tile >= 8 ? (J->dephase >> 1) : 0);
-    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    const int us = steps_per_tile >= 64 ? J->dephase : (steps_per_tile >= 8 ? (J->dephase >> 2) : 0);
+    if (us > 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = 100ull * (unsigned long long)min(us, 20000);
+      while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    }
   }
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
   const int s_begin = step0 + tile_idx * steps_per_tile;
@@ -2262,6 +2270,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     handoff_barrier();
     tr(c, 63);
   }
+  if ((flags & 64) && blockIdx.y == 0 && blockIdx.x < 512 && threadIdx.x == 0) nm_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- regression head (cVAE.py:2249-2253 regressor, 2318-2321 forward, 2330-2346 loss) ----------------
@@ -3150,6 +3159,11 @@ int nm_trace_read(unsigned long long* out512, int reset) {
     e = hipMemcpyToSymbol(HIP_SYMBOL(nm_trace_cycles), z, sizeof(z));
   }
   return (int)e;
+}
+
+int nm_wgtimes_read(unsigned long long* out1024) {
+  if (!out1024) return -1;
+  return (int)hipMemcpyFromSymbol(out1024, HIP_SYMBOL(nm_wg_times), sizeof(unsigned long long) * 1024);
 }
 
 int nm_abi_sizes(int64_t* sizeof_job, int64_t* sizeof_modality) {
