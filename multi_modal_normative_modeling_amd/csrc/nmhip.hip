@@ -2239,7 +2239,13 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   // number of s_sleep(127), spread the workgroups over three steps instead of one -- tools/wg_spread.py).  The offset
   // is pure cost at the end of the launch, so short launches get less of it and very short ones none.
   {
-    const int us = steps_per_tile >= 64 ? J->dephase : (steps_per_tile >= 8 ? (J->dephase >> 2) : 0);
+#ifndef NM_FWD_DEPHASE_DIV
+#define NM_FWD_DEPHASE_DIV 4
+#endif
+    // (forward only, many row tiles: the first workgroup of every CU -- tile 0 of each job -- starts late by a fraction
+    //  of a tile's time, the following tiles inherit the stagger)
+    int us = steps_per_tile >= 64 ? J->dephase : (steps_per_tile >= 8 ? (J->dephase >> 2) : 0);
+    if (MODE == 3) us = (NM_FWD_DEPHASE_DIV > 0 && tile_idx == 0 && gridDim.y > 1) ? J->dephase / NM_FWD_DEPHASE_DIV : 0;
     if (us > 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = 100ull * (unsigned long long)min(us, 20000);
       while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
