@@ -250,11 +250,13 @@ def test_regression_model_matches_reference():
     assert ok, worst
 
 
-def test_regression_head_multichunk_vs_oracle():
-    """nm_head_regression at a size whose concatenated residual spans several 128-column chunks, two of
-    them straddling a modality boundary, ragged batch: prediction, MSE, every regressor gradient and the
-    trunk gradients that receive d MSE / d x_hat, against the oracle with the kernel's operand rounding."""
-    dims, hidden, Z, cdim, B = [150, 90, 131], [48, 32], 10, 2, 200
+@pytest.mark.parametrize("dims,hidden,B", [([150, 90, 131], [48, 32], 200), ([379, 379, 379], [110, 110], 256)])
+def test_regression_head_multichunk_vs_oracle(dims, hidden, B):
+    """The regression model at sizes whose residual spans several 64-column chunks per modality with ragged last chunks
+    (and a ragged batch), and at the full 3 x 379 shape of the regression script: prediction, MSE, every regressor
+    gradient and the trunk gradients that receive d MSE / d x_hat, against the oracle with the kernel's operand
+    rounding (one launch: nm_train_steps_head with NM_F_GRADS)."""
+    Z, cdim = 10, 2
     torch.manual_seed(5)
     model = nm.cVAE_multimodal_regression(dims, hidden, Z, cdim, learning_rate=1e-4, modalities=3, non_linear=True)
     model.to(DEV)
