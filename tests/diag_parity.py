@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU diagnostic (not a test): per-tensor error of the HIP path against the fp32 oracle/golden and
-against the oracle in bf16-operand mode.  Usage: python tools/diag_parity.py [case ...]"""
+against the oracle in bf16-operand mode.  Usage: python tests/diag_parity.py [case ...]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
