@@ -8,10 +8,12 @@ The five CSV kinds of the test script (multimodal_kfold_test_cvae_supervised.py:
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Dict, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import pandas as pd
+
+from . import prep
 
 META_COLS = ["participant_id", "DIA", "AGE", "PTGENDER"]
 
@@ -60,3 +62,68 @@ def write_test_csvs(out_dir, dataset_name: str, covariates: pd.DataFrame, roi_co
     paths["deviation_as_feature_importance"] = out_dir / f"deviation_as_feature_importance_{dataset_name}.csv"
     fi.to_csv(paths["deviation_as_feature_importance"], index=False)
     return paths
+
+
+# ---- the reference's input layout -----------------------------------------------------------
+# data/<resource>/y.csv: IID, participant_id, DIA, AGE, PTGENDER (+ FI for HCPimage); data/<resource>/<modality>.csv:
+# IID + the ROI columns.  multimodal_kfold_train_cvae_supervised.py:49-50, 84-91 and utils.py:110-168 read them per
+# fold and modality through pd.merge on IID; here they are read once into a prep.Cohort.
+_NON_ROI = ("IID", "participant_id", "DIA", "AGE", "PTGENDER", "FI", "Session_ID", "Run_ID")
+
+
+def read_cohort(resource_dir, resource: str = "HCPimage", modalities: Optional[Sequence[str]] = None) -> prep.Cohort:
+    """y.csv (rows with missing values dropped, utils.py:124) inner-merged on IID with every modality table of the
+    resource (get_datasets_name order).  Rows follow the first modality's file (pd.merge keeps the left table's order,
+    utils.py:117); the other modalities are aligned to it by IID -- the reference feeds the modalities' DataLoaders side by
+    side and so assumes the files agree.  ROI columns = every column of the modality file that is not an id / covariate,
+    in file order.  DIA is mapped to the cohort's convention 1 = healthy control through get_hc_label (utils.py:760-774).
+    A missing FI column (only HCPimage carries it) reads as zeros."""
+    resource_dir = Path(resource_dir)
+    if resource not in prep.DATASET_MODALITIES:
+        raise ValueError("Unknown dataset: {}".format(resource))
+    names = list(modalities) if modalities is not None else [m for m in prep.DATASET_MODALITIES[resource]
+                                                             if (resource_dir / f"{m}.csv").exists()]
+    if not names:
+        raise FileNotFoundError(f"no modality tables of {resource} under {resource_dir}")
+    y = pd.read_csv(resource_dir / "y.csv").dropna()
+    for col in ("IID", "DIA", "AGE", "PTGENDER"):
+        if col not in y.columns:
+            raise ValueError(f"{resource_dir / 'y.csv'} has no column {col!r}")
+    tables = {m: pd.read_csv(resource_dir / f"{m}.csv") for m in names}
+    keep = set(y["IID"])
+    for t in tables.values():
+        keep &= set(t["IID"])
+    first = tables[names[0]]
+    order = [i for i in first["IID"].tolist() if i in keep]
+    if len(set(order)) != len(order):
+        raise ValueError(f"{names[0]}.csv repeats IIDs")
+    yi = y.drop_duplicates("IID").set_index("IID").loc[order]
+    x = {}
+    for m, t in tables.items():
+        roi = [c for c in t.columns if c not in _NON_ROI]
+        x[m] = t.drop_duplicates("IID").set_index("IID").loc[order, roi].to_numpy(dtype=np.float64)
+    hc = prep.HC_LABEL[resource]
+    fi = yi["FI"].to_numpy(dtype=np.float64) if "FI" in yi.columns else np.zeros(len(order))
+    return prep.Cohort(iid=np.asarray(order), age=yi["AGE"].to_numpy(dtype=np.float64), gender=yi["PTGENDER"].to_numpy(dtype=np.float64),
+                       dia=(yi["DIA"].to_numpy() == hc).astype(np.int64), fi=fi, x=x, resource=resource)
+
+
+def write_cohort(cohort: prep.Cohort, resource_dir, roi_names: Optional[dict] = None) -> None:
+    """The inverse of read_cohort: a cohort (e.g. the synthetic one) in the reference's ./data/<resource>/ layout, plus
+    the early-fusion table the way early_fusion_modalities.py:23-35 builds it (columns `<roi>_<modality>`, modality-major)."""
+    resource_dir = Path(resource_dir)
+    resource_dir.mkdir(parents=True, exist_ok=True)
+    hc = prep.HC_LABEL[cohort.resource]
+    dia = np.where(np.asarray(cohort.dia) == 1, hc, 0)
+    pd.DataFrame({"IID": cohort.iid, "participant_id": cohort.iid, "DIA": dia, "AGE": cohort.age, "PTGENDER": cohort.gender,
+                  "FI": cohort.fi}).to_csv(resource_dir / "y.csv", index=False)
+    fused = []
+    for m, xm in cohort.x.items():
+        cols = list(roi_names[m]) if roi_names and m in roi_names else [f"ROI_{i}" for i in range(xm.shape[1])]
+        df = pd.DataFrame(xm, columns=cols)
+        df.insert(0, "IID", cohort.iid)
+        df.to_csv(resource_dir / f"{m}.csv", index=False)
+        fused.append(pd.DataFrame(xm, columns=[f"{c}_{m}" for c in cols]))
+    fdf = pd.concat(fused, axis=1)
+    fdf.insert(0, "IID", cohort.iid)
+    fdf.to_csv(resource_dir / f"{cohort.fusion_name}.csv", index=False)

@@ -32,7 +32,7 @@ class DeviceCohort:
 
     def _sources(self, modality: str):
         """(device array of source pointers, device array of widths, n_src, D) -- several sources = early fusion."""
-        names = list(prep.HCP_MODALITIES) if modality == prep.EARLY_FUSION else [modality]
+        names = self.cohort.modalities if (modality not in self.x and prep.is_fusion(modality)) else [modality]
         tens = [self.x[n] for n in names]
         ptrs = torch.tensor([t.data_ptr() for t in tens], dtype=torch.int64, device=self.device)
         widths = torch.tensor([t.shape[1] for t in tens], dtype=torch.int32, device=self.device)

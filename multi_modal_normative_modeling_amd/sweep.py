@@ -41,20 +41,23 @@ class Cell:
     proc_id: int
     procedure: str
     replica: int = 0
+    resource: str = "HCPimage"
 
     @property
     def cost(self) -> float:
-        mods, _ = workload.procedure_modalities(self.procedure)
-        dims = [379 * 3 if m == prep.EARLY_FUSION else 379 for m in mods]
+        # (relative cost only: every base modality counted at the HCPimage width, the early-fusion table as their sum)
+        mods, _ = workload.procedure_modalities(self.procedure, self.resource)
+        n_base = len(prep.DATASET_MODALITIES.get(self.resource, prep.HCP_MODALITIES))
+        dims = [379 * n_base if prep.is_fusion(m) else 379 for m in mods]
         return workload.step_work(dims)["bytes"]
 
 
-def plan_cells(procedures: Sequence[str], n_folds: int, replicas: int = 1) -> List[Cell]:
+def plan_cells(procedures: Sequence[str], n_folds: int, replicas: int = 1, resource: str = "HCPimage") -> List[Cell]:
     cells, jid = [], 0
     for r in range(replicas):
         for p_id, proc in enumerate(procedures):
             for k in range(n_folds):
-                cells.append(Cell(jid, k, p_id, proc, r))
+                cells.append(Cell(jid, k, p_id, proc, r, resource))
                 jid += 1
     return cells
 
@@ -106,7 +109,7 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
     from .prep_device import DeviceCohort
     dc = DeviceCohort(cohort, device)
     for c in cells:
-        mods, combine = workload.procedure_modalities(c.procedure)
+        mods, combine = workload.procedure_modalities(c.procedure, cohort.resource)
         # (the DMVAE family's networks take no covariates: its tables are packed without the covariate block)
         tables = dc.fold_tables_cached(c.fold, mods, folds[c.fold][0], with_covariates=kind not in ("dmvae", "weighted_dmvae", "mmvaeplus"))
         spec = ModelSpec([t.D for t in tables], list(hidden), int(latent), workload.C_DIM, True, kind)
@@ -136,7 +139,7 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
     # (group_analysis_1x1.py:105-157); the ROI-wise matrices go to the host only when CSVs are asked for
     scores, finals = [], []
     dx = torch.as_tensor(cohort.dia == 0)
-    views = [(i, m, name) for i, c in enumerate(cells) for m, name in enumerate(workload.procedure_modalities(c.procedure)[0])]
+    views = [(i, m, name) for i, c in enumerate(cells) for m, name in enumerate(workload.procedure_modalities(c.procedure, cohort.resource)[0])]
     devs = deviation_roiwise_many([(jobs[i], m, name) for i, m, name in views], cohort, device, want_matrix=out_dir is not None)
     per_cell: Dict[int, list] = {}
     for (i, m, name), (dev, rowdev) in zip(views, devs):
@@ -173,7 +176,7 @@ def deviation_roiwise_many(views, cohort: prep.SyntheticCohort, device, want_mat
     for job, m, name in views:
         with_c = job.spec.net_c_dim > 0
         if (name, with_c) not in tables:
-            src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
+            src = prep.source_table(cohort, name)
             center, scale = prep.robust_scaler_fit(src.astype(np.float32))
             xs_ = prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32)
             tables[(name, with_c)] = Table(xs_, c if with_c else np.zeros((len(xs_), 0), dtype=np.float32), device)
@@ -206,7 +209,7 @@ def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str,
     and a scaler re-fit on all subjects -- exactly the pass of
     multimodal_kfold_train_cvae_supervised_regression.py:163-192.  Returns (ROI-wise matrix on the host or
     None, per-subject ROI-mean deviation on the device, IIDs)."""
-    src = cohort.x[name] if name in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
+    src = prep.source_table(cohort, name)
     center, scale = prep.robust_scaler_fit(src.astype(np.float32))
     x = prep.robust_scaler_transform(src.astype(np.float32), center, scale).astype(np.float32)
     c = prep.one_hot_covariates(cohort.age, cohort.gender) if covariates is None else covariates
@@ -373,7 +376,7 @@ def test_fold(job: Job, cohort: prep.SyntheticCohort, train_rows: np.ndarray, te
     {modality: per-subject reconstruction error} (what the group analysis averages and scores)."""
     xs = []
     for m in modalities:
-        src = cohort.x[m] if m in cohort.x else prep.early_fusion(cohort.x, prep.HCP_MODALITIES)
+        src = prep.source_table(cohort, m)
         center, scale = prep.robust_scaler_fit(src[train_rows])
         xs.append(prep.robust_scaler_transform(src[test_rows], center, scale).astype(np.float32))
     cov = prep.one_hot_covariates(cohort.age[test_rows], cohort.gender[test_rows])
@@ -425,6 +428,9 @@ def build_parser():
                     help="accepted for compatibility: the train script's cyclic schedule never reaches the optimizer (it assigns an "
                          "attribute Adam does not read, :180-186), so training runs at the base rate there and here")
     ap.add_argument("-TrainingClass", "--training_class", dest="training_class", type=str, default="nm")
+    ap.add_argument("--data-dir", dest="data_dir", type=str, default=None,
+                    help="root of the reference's data layout: <data-dir>/<dataset_resourse>/y.csv and one <modality>.csv per "
+                         "modality (IID + ROI columns); default: the synthetic cohort of SURVEY.md 8(d)")
     ap.add_argument("--subjects", type=int, default=1280, help="synthetic cohort size")
     ap.add_argument("--replicas", type=int, default=1, help="independent seeds per (fold, procedure) cell")
     ap.add_argument("--out-dir", type=str, default=None, help="deviation_fold_*_roiwise.csv + sweep_metrics.csv go here")
@@ -445,8 +451,10 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
         procedures = [f"SM-{args.single_modality}"]
     if args.combine:
         procedures = [p if p.startswith("SM-") else f"{p.split('-')[0]}-{args.combine}" for p in procedures]
+    if args.dataset_resourse not in prep.DATASET_MODALITIES:
+        raise ValueError("Unknown dataset: {}".format(args.dataset_resourse))   # utils.py:749
     for p in procedures:
-        workload.procedure_modalities(p)                                      # raises on an unknown procedure
+        workload.procedure_modalities(p, args.dataset_resourse)               # raises on an unknown procedure
     hidden, latent = list(args.hz_para_list[:-1]), int(args.hz_para_list[-1])
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -463,8 +471,18 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         started = True
-    cohort = prep.synthetic_cohort(n=args.subjects, d=379)
-    cells = plan_cells(procedures, args.n_splits, args.replicas)
+    if args.data_dir is not None:
+        # the reference's ./data/<resource>/ layout (y.csv + one CSV per modality)
+        from . import io as nm_io
+        cohort = nm_io.read_cohort(Path(args.data_dir) / args.dataset_resourse, args.dataset_resourse)
+    else:
+        cohort = prep.synthetic_cohort(n=args.subjects, d=379, modalities=prep.DATASET_MODALITIES[args.dataset_resourse],
+                                       resource=args.dataset_resourse)
+    for p in procedures:
+        missing = [m for m in workload.procedure_modalities(p, args.dataset_resourse)[0] if not prep.is_fusion(m) and m not in cohort.x]
+        if missing:
+            raise ValueError(f"procedure {p}: the cohort has no table for {missing} (has {cohort.modalities})")
+    cells = plan_cells(procedures, args.n_splits, args.replicas, args.dataset_resourse)
     mine = assign(cells, rank, world)
     out_dir = None
     if args.out_dir is not None:

@@ -180,6 +180,23 @@ def test_sweep_cli_zoo_models(model):
         sweep.main(["-Model", "nope", "--subjects", "32"])
 
 
+def test_sweep_cli_on_reference_data_layout():
+    """The sweep entry on a cohort stored in the reference's ./data/<resource>/ layout (y.csv + one CSV per modality),
+    for a resource other than HCPimage: -R ADNI -P UCA-gPoE SM-vbm --data-dir ...: tables built on the device from the
+    CSV-read cohort, training, deviation pass, ROI-wise CSVs named after ADNI's modalities and its early-fusion table."""
+    from multi_modal_normative_modeling_amd import io as nm_io
+    with tempfile.TemporaryDirectory() as d:
+        co = prep.synthetic_cohort(n=300, d=90, modalities=prep.DATASET_MODALITIES["ADNI"], resource="ADNI")
+        nm_io.write_cohort(co, f"{d}/data/ADNI")
+        table = sweep.main(["-R", "ADNI", "-P", "UCA-gPoE", "SM-vbm", "-E", "2", "-K", "2", "--data-dir", f"{d}/data", "--out-dir", f"{d}/out"])
+        assert table.shape == (4, sweep.N_METRICS) and torch.isfinite(table).all()
+        for name in ("av45", "vbm", "fdg", "early_fusion_modalities_ADNI"):
+            df = pd.read_csv(f"{d}/out/ADNI/UCA-gPoE/deviation_fold_1_{name}_roiwise.csv")
+            assert df.shape == (300, 1 + (270 if name.startswith("early") else 90)) and list(df.columns[:2]) == ["IID", "ROI_0"]
+            assert np.array_equal(df["IID"].to_numpy(), co.iid)
+        assert pd.read_csv(f"{d}/out/ADNI/SM-vbm/deviation_fold_0_vbm_roiwise.csv").shape == (300, 91)
+
+
 def test_sweep_end_to_end_small():
     """Two cells, a few epochs on a 320-subject synthetic cohort: training lowers the loss, the
     deviation CSVs have the reference layout and bit-exact IID / ROI indexing."""

@@ -143,3 +143,59 @@ def test_evaluate_regression_matches_sklearn():
     assert abs(got["MAE"] - mean_absolute_error(t, p)) < 1e-5
     assert abs(got["R2"] - r2_score(t, p)) < 1e-6
     assert abs(got["MAPE"] - np.mean(np.abs((t - p) / (t + 1e-6))) * 100) < 1e-4
+
+
+def test_cohort_reads_from_the_reference_data_layout(tmp_path):
+    """io.read_cohort on ./data/<resource>/ (y.csv + one CSV per modality): a cohort written in
+    that layout comes back identical (tables, covariates, healthy-control flag through get_hc_label, row order of the
+    first modality file, subjects missing from any file or with missing covariates dropped); the early-fusion table is
+    the modality-major concat either way; the sweep entry takes it through --data-dir for any -R of the reference."""
+    import pandas as pd
+    from multi_modal_normative_modeling_amd import io as nm_io
+    for resource in ("HCPimage", "ADNI"):
+        mods = prep.DATASET_MODALITIES[resource]
+        co = prep.synthetic_cohort(n=40, d=7, modalities=mods, resource=resource)
+        d = tmp_path / resource
+        nm_io.write_cohort(co, d)
+        back = nm_io.read_cohort(d, resource)
+        assert back.modalities == mods and back.resource == resource
+        assert np.array_equal(back.iid, co.iid) and np.array_equal(back.dia, co.dia)
+        assert np.array_equal(back.age, co.age) and np.array_equal(back.gender, co.gender)
+        for m in mods:
+            assert np.allclose(back.x[m], co.x[m], rtol=0, atol=1e-12)
+        fused = pd.read_csv(d / f"{prep.FUSION_PREFIX}{resource}.csv")
+        assert list(fused.columns[:3]) == ["IID", f"ROI_0_{mods[0]}", f"ROI_1_{mods[0]}"]
+        assert np.allclose(fused.iloc[:, 1:].to_numpy(), prep.source_table(back, back.fusion_name), atol=1e-12)
+        assert prep.datasets_name(resource, "UCA-gPoE") == mods + [prep.FUSION_PREFIX + resource]
+        assert prep.datasets_name(resource, f"SM-{mods[1]}") == [mods[1]]
+    # ADNI's healthy label is 2 (utils.py:760-774)
+    y = pd.read_csv(tmp_path / "ADNI" / "y.csv")
+    assert set(y["DIA"].unique()) <= {0, 2}
+    # a subject missing from one modality file, one with a missing covariate, and a shuffled second file
+    d = tmp_path / "HCPimage"
+    t2 = pd.read_csv(d / "T2w_sMRI.csv").sample(frac=1.0, random_state=1)
+    t2 = t2[t2["IID"] != co.iid[3]]
+    t2.to_csv(d / "T2w_sMRI.csv", index=False)
+    y = pd.read_csv(d / "y.csv")
+    y.loc[y["IID"] == co.iid[5], "AGE"] = np.nan
+    y.to_csv(d / "y.csv", index=False)
+    full = prep.synthetic_cohort(n=40, d=7)
+    back = nm_io.read_cohort(d, "HCPimage")
+    keep = np.array([i for i in range(40) if i not in (3, 5)])
+    assert np.array_equal(back.iid, full.iid[keep])
+    assert np.allclose(back.x["T2w_sMRI"], full.x["T2w_sMRI"][keep], atol=1e-12) and np.allclose(back.x["fMRI"], full.x["fMRI"][keep], atol=1e-12)
+    with pytest.raises(ValueError):
+        nm_io.read_cohort(d, "nope")
+    # the CLI: -R ADNI --data-dir <root> plans the ADNI modalities
+    seen = {}
+
+    def stub(cohort, cells, n_splits, epochs, device, **kw):
+        seen["cohort"], seen["cells"] = cohort, cells
+        return torch.zeros(len(cells), sweep.N_METRICS)
+    sweep.main(["-R", "ADNI", "-P", "UCA-gPoE", "SM-vbm", "-K", "2", "--data-dir", str(tmp_path)], _run_cells=stub)
+    assert seen["cohort"].resource == "ADNI" and seen["cohort"].modalities == ["av45", "vbm", "fdg"]
+    assert [c.procedure for c in seen["cells"]] == ["UCA-gPoE"] * 2 + ["SM-vbm"] * 2 and seen["cells"][0].resource == "ADNI"
+    with pytest.raises(ValueError):
+        sweep.main(["-R", "ADNI", "-P", "SM-T1w_sMRI", "--data-dir", str(tmp_path)], _run_cells=stub)
+    with pytest.raises(ValueError):
+        sweep.main(["-R", "XYZ", "--subjects", "32"], _run_cells=stub)
