@@ -9,6 +9,7 @@ CPU tests) -- there is no data-path exchange.
 """
 from __future__ import annotations
 
+import argparse
 import time
 from dataclasses import dataclass
 from pathlib import Path
@@ -254,8 +255,8 @@ def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[in
         tr = folds[k][0]
         xs, sc = [], []
         for m in modalities:
-            center, scale = prep.robust_scaler_fit(cohort.x[m][tr])
-            xs.append(prep.robust_scaler_transform(cohort.x[m][tr], center, scale).astype(np.float32))
+            center, scale = prep.robust_scaler_fit(prep.source_table(cohort, m)[tr])
+            xs.append(prep.robust_scaler_transform(prep.source_table(cohort, m)[tr], center, scale).astype(np.float32))
             sc.append((center, scale))
         scalers.append(sc)
         tables = [Table(x, cov_all[tr], device) for x in xs]
@@ -275,7 +276,7 @@ def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[in
     for k, j, sc in zip(folds_to_run, jobs, scalers):
         te = folds[k][1]
         # held-out FI prediction (:127-149): joint posterior, sampled z
-        xs = [prep.robust_scaler_transform(cohort.x[m][te], *sc[i]).astype(np.float32) for i, m in enumerate(modalities)]
+        xs = [prep.robust_scaler_transform(prep.source_table(cohort, m)[te], *sc[i]).astype(np.float32) for i, m in enumerate(modalities)]
         tables = [Table(x, cov_all[te], device) for x in xs]
         ev = Job(j.spec, tables, combine=combine, state=j.state_dict(), seed=j.seed + 17, n_tiles_ws=tables[0].n_tiles)
         ev.enable_exports(loc=True, sqerr=False, rowdev=False, latent=False)
@@ -320,8 +321,8 @@ def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int]
         tr = folds[k][0]
         xs, sc = [], []
         for m in modalities:
-            center, scale = prep.robust_scaler_fit(cohort.x[m][tr])
-            xs.append(prep.robust_scaler_transform(cohort.x[m][tr], center, scale).astype(np.float32))
+            center, scale = prep.robust_scaler_fit(prep.source_table(cohort, m)[tr])
+            xs.append(prep.robust_scaler_transform(prep.source_table(cohort, m)[tr], center, scale).astype(np.float32))
             sc.append((center, scale))
         scalers.append(sc)
         cov = prep.one_hot_covariates(cohort.age[tr], cohort.gender[tr])
@@ -343,7 +344,7 @@ def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int]
     preds, labs, finals = [], [], []
     for k, j, sc in zip(folds_to_run, jobs, scalers):
         te = folds[k][1]
-        xs = [prep.robust_scaler_transform(cohort.x[m][te], *sc[i]).astype(np.float32) for i, m in enumerate(modalities)]
+        xs = [prep.robust_scaler_transform(prep.source_table(cohort, m)[te], *sc[i]).astype(np.float32) for i, m in enumerate(modalities)]
         cov = prep.one_hot_covariates(cohort.age[te], cohort.gender[te])           # re-binned on the test rows (:203-209)
         tables = [Table(x, cov, device) for x in xs]
         ev = Job(j.spec, tables, combine="poe", state=j.state_dict(), seed=j.seed + 17, single_bypass=False,
@@ -515,5 +516,115 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     return table if rank == 0 else torch.empty(0, N_METRICS)
 
 
+def _cohort_from_args(args) -> prep.Cohort:
+    if args.dataset_resourse not in prep.DATASET_MODALITIES:
+        raise ValueError("Unknown dataset: {}".format(args.dataset_resourse))   # utils.py:749
+    if args.data_dir is not None:
+        from . import io as nm_io
+        return nm_io.read_cohort(Path(args.data_dir) / args.dataset_resourse, args.dataset_resourse)
+    return prep.synthetic_cohort(n=args.subjects, d=379, modalities=prep.DATASET_MODALITIES[args.dataset_resourse],
+                                 resource=args.dataset_resourse)
+
+
+def _driver_common(ap: argparse.ArgumentParser):
+    ap.add_argument("--data-dir", dest="data_dir", type=str, default=None, help="root of the reference's data layout (see the train entry)")
+    ap.add_argument("--subjects", type=int, default=1280, help="synthetic cohort size when no --data-dir is given")
+    ap.add_argument("--out-dir", type=str, default=None)
+    ap.add_argument("--folds", nargs="+", type=int, default=None, help="folds to run (default: all; under torch.distributed.run: this rank's share)")
+
+
+def _my_folds(args) -> List[int]:
+    import os
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    folds = list(range(args.n_splits)) if args.folds is None else list(args.folds)
+    return folds[rank::world]
+
+
+def main_regression(argv=None, _runner=None):
+    """Command line of multimodal_kfold_train_cvae_supervised_regression.py:196-206 (same flag names): FI regression model
+    on the folds of a cohort, every fold training concurrently in one launch; under torch.distributed.run the folds are
+    dealt round-robin to the ranks (no collective: each rank writes its folds' files).  Returns the per-fold results."""
+    import os
+    ap = argparse.ArgumentParser(prog="python -m multi_modal_normative_modeling_amd.sweep regression", description=main_regression.__doc__)
+    ap.add_argument("-R", "--dataset_resourse", dest="dataset_resourse", type=str, default="HCPimage",
+                    help="(the reference defaults to ADNI, whose y.csv carries no FI column; HCPimage is the resource with FI)")
+    ap.add_argument("-H", "--hz_para_list", dest="hz_para_list", nargs="+", type=int, default=[110, 110, 10])
+    ap.add_argument("-C", "--combine", dest="combine", type=str, default="gpoe")
+    ap.add_argument("-P", "--procedure", dest="procedure", type=str, default="UCA-gPoE")
+    ap.add_argument("-E", "--epochs", dest="epochs", type=int, default=500)
+    ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=5)
+    ap.add_argument("--batch_size", type=int, default=128,
+                    help="accepted for compatibility: a step takes 256 rows (the tile the kernel is built around)")
+    ap.add_argument("-BaseLR", "--base_learning_rate", dest="base_learning_rate", type=float, default=1e-4)
+    _driver_common(ap)
+    args = ap.parse_args(argv)
+    if list(args.hz_para_list) != list(workload.HIDDEN) + [workload.LATENT]:
+        raise ValueError("the regression driver is built for -H 110 110 10 (workload.HIDDEN / LATENT)")
+    cohort = _cohort_from_args(args)
+    mods = prep.datasets_name(args.dataset_resourse, args.procedure)
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    out_dir = None if args.out_dir is None else Path(args.out_dir) / args.dataset_resourse / "regression_outputs"
+    runner = _runner or run_regression_folds
+    res = runner(cohort, _my_folds(args), args.n_splits, args.epochs, device, out_dir=out_dir, modalities=mods,
+                 combine=args.combine.lower(), lr=args.base_learning_rate)
+    for r in res:
+        print("[regression] " + "  ".join(f"{k} {v:.5g}" if isinstance(v, float) else f"{k} {v}" for k, v in r.items()), flush=True)
+    return res
+
+
+def main_endtoend(argv=None, _runner=None):
+    """Command line of multimodal_kfold_cvae_nmpmcont.py:344-445 (same flag names): the end-to-end model (shared encoders,
+    PoE, health / disease decoder banks, classifier with cross entropy + contrastive hinge) on the folds of a cohort,
+    every fold training concurrently in one launch, evaluate() on the held-out fold.  Flags the script parses but never
+    uses (-C, -O, -Model, -Maxlearningrate, -Learningrateclassifier, -Weightkl, -Weightrec: its loss call passes margin and
+    weightcontrastive only, :298) are accepted and ignored the same way."""
+    import os
+    ap = argparse.ArgumentParser(prog="python -m multi_modal_normative_modeling_amd.sweep endtoend", description=main_endtoend.__doc__)
+    ap.add_argument("-R", "--dataset_resourse", dest="dataset_resourse", type=str, default="HCPimage")
+    ap.add_argument("-H", "--hz_para_list", dest="hz_para_list", nargs="+", type=int, default=[110, 110, 64])
+    ap.add_argument("-C", "--combine", dest="combine", type=str, default="poe")
+    ap.add_argument("-P", "--procedure", dest="procedure", type=str, default="SE-PoE")
+    ap.add_argument("-E", "--epochs", dest="epochs", type=int, default=50)
+    ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=5)
+    ap.add_argument("-O", "--oversample_percentage", dest="oversample_percentage", type=float, default=1)
+    ap.add_argument("-Model", "--model", dest="model", type=str, default="cVAE_multimodal")
+    ap.add_argument("-SingleModality", "--single_modality", dest="single_modality", type=str, default=None)
+    ap.add_argument("-Baselearningrate", "--base_learning_rate", dest="base_learning_rate", type=float, default=1e-4)
+    ap.add_argument("-Maxlearningrate", "--max_learning_rate", dest="max_learning_rate", type=float, default=0.005)
+    ap.add_argument("-Learningrateclassifier", "--learning_rate_classifier", dest="learning_rate_classifier", type=float, default=0.001)
+    ap.add_argument("-Margin", "--margin", dest="margin", type=float, default=1)
+    ap.add_argument("-Weightcontrastive", "--weightcontrastive", dest="weightcontrastive", type=float, default=1)
+    ap.add_argument("-Weightkl", "--weight_kl", dest="weight_kl", type=float, default=1)
+    ap.add_argument("-Weightrec", "--weight_rec", dest="weight_rec", type=float, default=1)
+    ap.add_argument("-Dropout", "--dropout", dest="dropout", type=float, default=0.5)
+    ap.add_argument("-Layers", "--layers", dest="layers", nargs="+", type=int, default=[128, 64, 32])
+    _driver_common(ap)
+    args = ap.parse_args(argv)
+    if list(args.hz_para_list[:-1]) != list(workload.HIDDEN):
+        raise ValueError("the end-to-end driver is built for hidden widths 110 110 (workload.HIDDEN)")
+    cohort = _cohort_from_args(args)
+    proc = f"SM-{args.single_modality}" if args.single_modality else args.procedure
+    mods = [m for m in prep.datasets_name(args.dataset_resourse, proc)]
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    runner = _runner or run_endtoend_folds
+    res = runner(cohort, _my_folds(args), args.n_splits, args.epochs, device, modalities=mods, latent=int(args.hz_para_list[-1]),
+                 classifier_layers=tuple(args.layers), dropout_rate=args.dropout, margin=args.margin,
+                 weightcontrastive=args.weightcontrastive, lr=args.base_learning_rate, hc_label=1)
+    for r in res:
+        print("[endtoend] " + "  ".join(f"{k} {v:.5g}" if isinstance(v, float) else f"{k} {v}" for k, v in r.items()), flush=True)
+    if args.out_dir is not None and res:
+        import pandas as pd
+        out = Path(args.out_dir) / args.dataset_resourse
+        out.mkdir(parents=True, exist_ok=True)
+        pd.DataFrame(res).to_csv(out / f"endtoend_metrics_rank{int(os.environ.get('RANK', '0'))}.csv", index=False)
+    return res
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "regression":
+        main_regression(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "endtoend":
+        main_endtoend(sys.argv[2:])
+    else:
+        main()

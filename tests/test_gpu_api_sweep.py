@@ -197,6 +197,21 @@ def test_sweep_cli_on_reference_data_layout():
         assert pd.read_csv(f"{d}/out/ADNI/SM-vbm/deviation_fold_0_vbm_roiwise.csv").shape == (300, 91)
 
 
+def test_regression_and_endtoend_command_lines_one_gpu():
+    """`python -m ... sweep regression` / `endtoend` (the command lines of the regression and nmpmcont scripts) on one
+    GPU, small: UCA procedure = three modalities + their early-fusion table as the fourth expert of the regression
+    model; per-fold results, prediction files and ROI-wise CSVs come out."""
+    with tempfile.TemporaryDirectory() as d:
+        res = sweep.main_regression(["-P", "UCA-gPoE", "-E", "2", "-K", "5", "--folds", "0", "3", "--subjects", "320", "--out-dir", d])
+        assert [r["fold"] for r in res] == [0, 3] and all(np.isfinite([r["RMSE"], r["final_mse"], r["final_total"]]).all() for r in res)
+        out = f"{d}/HCPimage/regression_outputs"
+        assert np.load(f"{out}/fold_3_pred.npy").shape == (64, 1)
+        assert pd.read_csv(f"{out}/deviation_fold_0_{prep.EARLY_FUSION}_roiwise.csv").shape == (320, 1 + 3 * 379)
+        res = sweep.main_endtoend(["-E", "2", "-K", "5", "--folds", "1", "--subjects", "320", "-Dropout", "0.2", "--out-dir", d])
+        assert len(res) == 1 and res[0]["fold"] == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
+        assert pd.read_csv(f"{d}/HCPimage/endtoend_metrics_rank0.csv").shape[0] == 1
+
+
 def test_sweep_end_to_end_small():
     """Two cells, a few epochs on a 320-subject synthetic cohort: training lowers the loss, the
     deviation CSVs have the reference layout and bit-exact IID / ROI indexing."""
