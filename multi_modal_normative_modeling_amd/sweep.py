@@ -87,7 +87,7 @@ def gather_metrics(local: torch.Tensor, max_rows: int, device=None) -> torch.Ten
 def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int, epochs: int, device, out_dir=None,
               lr: float = 1e-4, steps_per_launch: int = 64, oversample_percentage: Optional[float] = None,
               hidden: Sequence[int] = workload.HIDDEN, latent: int = workload.LATENT,
-              per_procedure_dirs: bool = False, model: str = "cVAE_multimodal") -> torch.Tensor:
+              per_procedure_dirs: bool = False, model: str = "cVAE_multimodal", models_dir=None) -> torch.Tensor:
     """Train the given cells concurrently, run the ROI-wise deviation pass, return the metric rows.
     `oversample_percentage` switches the training rows to the train script's own recipe (utils.generate_kfold_ids:
     KFold over healthy + other, bootstrap resample with replacement, merged back in table order); None = the plain
@@ -133,6 +133,11 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
         total_steps += n * len(idxs)
         js.assert_finite()
     torch.cuda.synchronize(device)
+    if models_dir is not None:
+        # what the train script leaves for the test script (cVAE_model.pkl per fold, ...train...py:211-212), as the
+        # state_dict under the reference's key names + the constructor arguments
+        for c, j in zip(cells, jobs):
+            save_model(Path(models_dir) / c.procedure / f"{c.fold:03d}", j, model)
     sps = total_steps / max(time.perf_counter() - t0, 1e-9)
     # deviation pass: ONE forward-only launch for every (cell, modality) of this rank (unimodal views of the trained
     # models on the all-subject tables, one workgroup per (view, 256-row tile)); the per-subject score (mean over
@@ -368,6 +373,30 @@ def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int]
     return out
 
 
+def save_model(fold_dir, job: Job, model: str = "cVAE_multimodal") -> Path:
+    """<fold_dir>/cVAE_model_state.pt: {'state_dict': reference-keyed tensors, 'input_dim_list', 'hidden_dim', 'latent_dim',
+    'c_dim', 'model', 'combine'} -- loadable by the reference class (`load_state_dict`) and by load_model."""
+    fold_dir = Path(fold_dir)
+    fold_dir.mkdir(parents=True, exist_ok=True)
+    sp = job.spec
+    path = fold_dir / "cVAE_model_state.pt"
+    torch.save({"state_dict": {k: v.cpu() for k, v in job.state_dict().items()}, "input_dim_list": list(sp.input_dims),
+                "hidden_dim": list(sp.hidden), "latent_dim": int(sp.latent), "c_dim": int(sp.c_dim), "model": model,
+                "combine": job.combine}, path)
+    return path
+
+
+def load_model(fold_dir, tables: Sequence[Table], device, seed: int = 0) -> Job:
+    """The Job of a model saved by save_model, on the given tables (their widths must match the saved input_dim_list)."""
+    ck = torch.load(Path(fold_dir) / "cVAE_model_state.pt", map_location="cpu", weights_only=True)
+    kind, bypass, _ = MODEL_KINDS[ck["model"]]
+    if [t.D for t in tables] != list(ck["input_dim_list"]):
+        raise ValueError(f"tables of widths {[t.D for t in tables]} for a model trained on {ck['input_dim_list']}")
+    spec = ModelSpec(list(ck["input_dim_list"]), list(ck["hidden_dim"]), int(ck["latent_dim"]), int(ck["c_dim"]), True, kind)
+    return Job(spec, list(tables), combine=ck["combine"], state=ck["state_dict"], seed=seed, single_bypass=bypass,
+               n_tiles_ws=tables[0].n_tiles)
+
+
 def test_fold(job: Job, cohort: prep.SyntheticCohort, train_rows: np.ndarray, test_rows: np.ndarray, modalities: Sequence[str],
               combine: str, device, out_dir=None, roi_columns: Optional[Dict[str, Sequence[str]]] = None):
     """One fold of multimodal_kfold_test_cvae_supervised.py:64-153 for a trained model: per modality a RobustScaler
@@ -436,6 +465,8 @@ def build_parser():
     ap.add_argument("--replicas", type=int, default=1, help="independent seeds per (fold, procedure) cell")
     ap.add_argument("--out-dir", type=str, default=None, help="deviation_fold_*_roiwise.csv + sweep_metrics.csv go here")
     ap.add_argument("--no-csv", action="store_true", help="skip the ROI-wise CSVs (metrics only)")
+    ap.add_argument("--save-models", action="store_true",
+                    help="write <out-dir>/<resource>/<procedure>/<fold:03d>/cVAE_model_state.pt (what the `test` subcommand loads)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend when WORLD_SIZE > 1 (nccl = RCCL)")
     return ap
 
@@ -492,7 +523,8 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     runner = _run_cells or run_cells
     oversample = None if args.oversample_percentage == 1.0 and args.training_class == "nm" else args.oversample_percentage
     # run_cells writes a cell's CSVs into <out>/<procedure>/ when procedures share modalities (per_procedure_dirs)
-    kw = {} if _run_cells is not None else {"per_procedure_dirs": True, "model": args.model}
+    kw = {} if _run_cells is not None else {"per_procedure_dirs": True, "model": args.model,
+                                            "models_dir": out_dir if (args.save_models and out_dir is not None) else None}
     local = runner(cohort, mine, args.n_splits, args.epochs, device, out_dir=None if args.no_csv else out_dir,
                    lr=args.base_learning_rate, oversample_percentage=oversample, hidden=hidden, latent=latent, **kw)
     max_rows = (len(cells) + world - 1) // world
@@ -620,11 +652,63 @@ def main_endtoend(argv=None, _runner=None):
     return res
 
 
+def main_test(argv=None):
+    """Command line of multimodal_kfold_test_cvae_supervised.py:180-187 (-R -H -C -P -K): for every fold of a procedure load
+    the model the train entry saved (--save-models), scale the fold's test rows with the scaler of its train rows, re-bin
+    the covariates on the test rows, reconstruct from the joint latent and write the five CSV kinds per modality under
+    <models-dir>/<resource>/<procedure>/<fold:03d>/<modality>/, then the all-folds tables under
+    <out-dir>/<resource>/<procedure>/<modality>/ (the script's deviation_dir, :147-175).  Returns {modality: [N] errors}."""
+    import os
+    import pandas as pd
+    ap = argparse.ArgumentParser(prog="python -m multi_modal_normative_modeling_amd.sweep test", description=main_test.__doc__)
+    ap.add_argument("-R", "--dataset_resourse", dest="dataset_resourse", type=str, default="HCPimage")
+    ap.add_argument("-H", "--hz_para_list", dest="hz_para_list", nargs="+", type=int, default=[110, 110, 10])
+    ap.add_argument("-C", "--combine", dest="combine", type=str, default=None)
+    ap.add_argument("-P", "--procedure", dest="procedure", type=str, default="SE-gPoE")
+    ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=10)
+    ap.add_argument("--models-dir", type=str, required=True, help="the --out-dir of the train entry (run with --save-models)")
+    _driver_common(ap)
+    args = ap.parse_args(argv)
+    cohort = _cohort_from_args(args)
+    mods, combine = workload.procedure_modalities(args.procedure, args.dataset_resourse)
+    combine = (args.combine or combine).lower()
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    folds = prep.kfold_indices(len(cohort.iid), args.n_splits, 42)
+    root = Path(args.models_dir) / args.dataset_resourse / args.procedure
+    out_root = Path(args.out_dir or args.models_dir) / args.dataset_resourse / args.procedure
+    from .prep_device import DeviceCohort
+    dc = DeviceCohort(cohort, device)
+    errors: Dict[str, list] = {m: [] for m in mods}
+    my = _my_folds(args)
+    for k in my:
+        tr, te = folds[k]
+        fold_dir = root / f"{k:03d}"
+        # (the model is rebuilt on any tables of the right widths; test_fold puts it on the fold's test tables)
+        meta = torch.load(fold_dir / "cVAE_model_state.pt", map_location="cpu", weights_only=True)
+        no_cov = MODEL_KINDS[meta["model"]][0] in ("dmvae", "weighted_dmvae", "mmvaeplus")
+        job = load_model(fold_dir, dc.fold_tables_cached(k, mods, tr, with_covariates=not no_cov), device, seed=1000 * k)
+        err = test_fold(job, cohort, tr, te, mods, combine, device, out_dir=fold_dir)
+        for m in mods:
+            errors[m].append(err[m])
+    for m in mods:                                   # all folds of this rank, one table per CSV kind (:147-175)
+        (out_root / m).mkdir(parents=True, exist_ok=True)
+        for kind in ("normalized", "reconstruction", "reconstruction_error", "reconstruction_error_roi", "deviation_as_feature_importance"):
+            parts = [pd.read_csv(root / f"{k:03d}" / m / f"{kind}_{m}.csv") for k in my]
+            if parts:
+                pd.concat(parts, ignore_index=True).to_csv(out_root / m / f"{kind}_{m}.csv", index=False)
+    out = {m: np.concatenate(v) if v else np.empty(0) for m, v in errors.items()}
+    for m, v in out.items():
+        print(f"[test] {args.procedure} {m}: {len(v)} subjects, mean reconstruction error {float(v.mean()) if len(v) else float('nan'):.5f}", flush=True)
+    return out
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "regression":
         main_regression(sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "endtoend":
         main_endtoend(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "test":
+        main_test(sys.argv[2:])
     else:
         main()

@@ -212,6 +212,29 @@ def test_regression_and_endtoend_command_lines_one_gpu():
         assert pd.read_csv(f"{d}/HCPimage/endtoend_metrics_rank0.csv").shape[0] == 1
 
 
+def test_train_then_test_command_lines():
+    """The train entry with --save-models followed by the `test` subcommand (multimodal_kfold_test_cvae_supervised.py): the
+    saved state_dict carries the reference's key names, the test run reloads it per fold and writes the five CSV kinds per
+    modality per fold and for all folds together; the reconstruction error column equals the ROI mean of the ROI-wise one."""
+    with tempfile.TemporaryDirectory() as d:
+        sweep.main(["-P", "SE-gPoE", "-E", "3", "-K", "2", "--subjects", "300", "--out-dir", d, "--save-models", "--no-csv"])
+        ck = torch.load(f"{d}/HCPimage/SE-gPoE/001/cVAE_model_state.pt", weights_only=True)
+        assert ck["input_dim_list"] == [379, 379, 379] and "encoder_list.0.encoder_layers.0.weight" in ck["state_dict"]
+        ref_keys = list(nm.cVAE_multimodal([379] * 3, [110, 110], 10, 29, modalities=3, non_linear=True).state_dict().keys())
+        assert list(ck["state_dict"].keys()) == ref_keys
+        errs = sweep.main_test(["-P", "SE-gPoE", "-K", "2", "--subjects", "300", "--models-dir", d])
+        assert set(errs) == set(prep.HCP_MODALITIES) and all(v.shape == (300,) and np.isfinite(v).all() for v in errs.values())
+        base = f"{d}/HCPimage/SE-gPoE"
+        for kind in ("normalized", "reconstruction", "reconstruction_error", "reconstruction_error_roi", "deviation_as_feature_importance"):
+            assert pd.read_csv(f"{base}/000/fMRI/{kind}_fMRI.csv").shape[0] == 150
+            assert pd.read_csv(f"{base}/fMRI/{kind}_fMRI.csv").shape[0] == 300
+        e = pd.read_csv(f"{base}/T1w_sMRI/reconstruction_error_T1w_sMRI.csv")
+        r = pd.read_csv(f"{base}/T1w_sMRI/reconstruction_error_roi_T1w_sMRI.csv")
+        assert list(e.columns) == ["participant_id", "DIA", "AGE", "PTGENDER", "Reconstruction error"]
+        assert np.allclose(e["Reconstruction error"].to_numpy(), r.iloc[:, 4:].to_numpy().mean(axis=1), rtol=1e-5)
+        assert np.allclose(e["Reconstruction error"].to_numpy(), errs["T1w_sMRI"], rtol=1e-4, atol=1e-6)
+
+
 def test_sweep_end_to_end_small():
     """Two cells, a few epochs on a 320-subject synthetic cohort: training lowers the loss, the
     deviation CSVs have the reference layout and bit-exact IID / ROI indexing."""
