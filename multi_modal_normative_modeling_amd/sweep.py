@@ -702,6 +702,52 @@ def main_test(argv=None):
     return out
 
 
+def main_analysis(argv=None):
+    """multimodal_kfold_cvae_group_analysis_1x1.py:160-235 on the files the `test` subcommand wrote: per fold the subjects'
+    reconstruction errors averaged over the procedure's modalities (:205-209), healthy vs disease ROC-AUC, Youden-J
+    threshold, accuracy / sensitivity / specificity (compute_classification_performance, :105-157, on the device:
+    nm_posthoc_metrics) and the significance ratio auc / (1 - auc) (:231); prints the per-fold rows and mean +- std,
+    writes <models-dir>/<resource>/<procedure>/group_analysis.csv.  Returns the [folds, 8] metric table."""
+    import pandas as pd
+    ap = argparse.ArgumentParser(prog="python -m multi_modal_normative_modeling_amd.sweep analysis", description=main_analysis.__doc__)
+    ap.add_argument("-R", "--dataset_resourse", dest="dataset_resourse", type=str, default="HCPimage")
+    ap.add_argument("-H", "--hz_para_list", dest="hz_para_list", nargs="+", type=int, default=[110, 110, 10])
+    ap.add_argument("-C", "--combine", dest="combine", type=str, default=None)
+    ap.add_argument("-P", "--procedure", dest="procedure", type=str, default="SE-gPoE")
+    ap.add_argument("-E", "--epochs", dest="epochs", type=int, default=None)
+    ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=10)
+    ap.add_argument("--models-dir", type=str, required=True, help="where the `test` subcommand wrote its per-fold CSVs")
+    args = ap.parse_args(argv)
+    mods, _ = workload.procedure_modalities(args.procedure, args.dataset_resourse)
+    root = Path(args.models_dir) / args.dataset_resourse / args.procedure
+    hc = prep.HC_LABEL.get(args.dataset_resourse, 1)
+    scores, positive, folds = [], [], []
+    for k in range(args.n_splits):
+        files = [root / f"{k:03d}" / m / f"reconstruction_error_{m}.csv" for m in mods]
+        if not all(f.exists() for f in files):
+            continue
+        dfs = [pd.read_csv(f) for f in files]
+        err = sum(d["Reconstruction error"].to_numpy(dtype=np.float64) for d in dfs) / len(dfs)
+        dia = dfs[0]["DIA"].to_numpy()
+        # (files written from a prep.Cohort carry DIA in the cohort's convention 1 = healthy; raw tables the resource's label)
+        healthy = (dia == 1) if set(np.unique(dia)) <= {0, 1} else (dia == hc)
+        scores.append(torch.as_tensor(err, dtype=torch.float32))
+        positive.append(torch.as_tensor(~healthy, dtype=torch.int32))
+        folds.append(k)
+    if not folds:
+        raise FileNotFoundError(f"no reconstruction_error_*.csv of {mods} under {root}/<fold>/ -- run the `test` subcommand first")
+    table = metrics.posthoc_metrics(scores, positive).cpu()
+    df = pd.DataFrame(table.numpy(), columns=list(metrics.POSTHOC_COLUMNS))
+    df.insert(0, "fold", folds)
+    df.to_csv(root / "group_analysis.csv", index=False)
+    for _, r in df.iterrows():
+        print(f"[analysis] fold {int(r['fold'])}: AUC {r['roc_auc']:.4f}  accuracy {r['accuracy']:.4f}  sensitivity {r['recall']:.4f}  "
+              f"specificity {r['specificity']:.4f}  significance ratio {r['significance_ratio']:.3f}", flush=True)
+    print(f"[analysis] {args.procedure}: AUC {df['roc_auc'].mean():.4f} +- {df['roc_auc'].std(ddof=0):.4f}  accuracy {df['accuracy'].mean():.4f}  "
+          f"sensitivity {df['recall'].mean():.4f}  specificity {df['specificity'].mean():.4f}", flush=True)
+    return table
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "regression":
@@ -710,5 +756,7 @@ if __name__ == "__main__":
         main_endtoend(sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "test":
         main_test(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "analysis":
+        main_analysis(sys.argv[2:])
     else:
         main()

@@ -233,6 +233,14 @@ def test_train_then_test_command_lines():
         assert list(e.columns) == ["participant_id", "DIA", "AGE", "PTGENDER", "Reconstruction error"]
         assert np.allclose(e["Reconstruction error"].to_numpy(), r.iloc[:, 4:].to_numpy().mean(axis=1), rtol=1e-5)
         assert np.allclose(e["Reconstruction error"].to_numpy(), errs["T1w_sMRI"], rtol=1e-4, atol=1e-6)
+        # the group-analysis script on those files: per-fold ROC metrics from the modality-averaged errors
+        from oracle import metrics_ref as MR
+        tab = sweep.main_analysis(["-P", "SE-gPoE", "-K", "2", "--models-dir", d]).numpy()
+        assert tab.shape == (2, 8) and pd.read_csv(f"{base}/group_analysis.csv").shape == (2, 9)
+        dfs = [pd.read_csv(f"{base}/001/{m}/reconstruction_error_{m}.csv") for m in prep.HCP_MODALITIES]
+        sc = sum(x["Reconstruction error"].to_numpy() for x in dfs) / 3
+        ref = MR.posthoc_metrics(sc.astype(np.float32), (dfs[0]["DIA"].to_numpy() != 1).astype(np.int32))
+        assert abs(tab[1, 0] - ref[0]) < 1e-9 and np.array_equal(tab[1, 2:5], np.asarray(ref[2:5]))
 
 
 def test_sweep_end_to_end_small():
