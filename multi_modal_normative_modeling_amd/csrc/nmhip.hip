@@ -2562,12 +2562,26 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
   // ---- P <- z (or the joint mean for predict) ----
   {
     const int Kz = rup(Z, 32);
-    const float rk = 1.0f / (float)Kz;
     gcf32 zsrc = asg((const float*)(J->cls_use_mu ? J->out_mu : J->out_z));
-    for (int e = c.tid; e < ROWS * Kz; e += WG) {
-      const int r = idiv(e, Kz, rk), k = e - r * Kz;
-      const float v = zsrc[(int64_t)(c.row0 + min(r, c.nrows - 1)) * Z + min(k, Z - 1)];
-      c.P[r * LDP + k] = (__bf16)((k < Z && r < c.nrows) ? v : 0.f);
+    if ((Z & 3) == 0) {                              // 16-byte pieces (rows are 16-byte aligned then)
+      const int nq = Kz >> 2;
+      const float rq = 1.0f / (float)nq;
+      for (int e = c.tid; e < ROWS * nq; e += WG) {
+        const int r = idiv(e, nq, rq), k = 4 * (e - r * nq);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < Z && r < c.nrows) v = *(const GAS f32x4*)(zsrc + (int64_t)(c.row0 + r) * Z + k);
+        bf16x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = (__bf16)v[i];
+        *reinterpret_cast<bf16x4*>(c.P + r * LDP + k) = pk;
+      }
+    } else {
+      const float rk = 1.0f / (float)Kz;
+      for (int e = c.tid; e < ROWS * Kz; e += WG) {
+        const int r = idiv(e, Kz, rk), k = e - r * Kz;
+        const float v = zsrc[(int64_t)(c.row0 + min(r, c.nrows - 1)) * Z + min(k, Z - 1)];
+        c.P[r * LDP + k] = (__bf16)((k < Z && r < c.nrows) ? v : 0.f);
+      }
     }
   }
   lds_barrier();
@@ -2578,12 +2592,28 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
     relaunder(c);
     const int K = li == 0 ? Z : J->cls_width[li - 1], N = J->cls_width[li], K32 = rup(K, 32);
     gcf32 Wl = prm + J->cls_w[li];
+    // the layer's weights as one coalesced block through registers into Q (free in the forward pass) and the BatchNorm
+    // affine parameters: all requested before anything waits (fragment loads from global inside the GEMM loop and
+    // parameter loads behind the statistics' barriers were most of this head's forward time)
+    WBlk<128> wb;
+    wblk_load<128>(c, wb, Wl, N, K, 0, 0);
+    float mean[2][4], rstd[2][4], gam[2][4], bet[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int fc = min((c.wn + 4 * t) * 16 + 4 * c.g + i, N - 1);
+        gam[t][i] = prm[J->cls_bn_w[li] + fc];
+        bet[t][i] = prm[J->cls_bn_b[li] + fc];
+      }
     if (bwd) store_act(c, W.hin[li], c.P, K32);
     bias_acc(c, acc, prm + J->cls_b[li], N, 0);
+    wblk_store<128>(c, wb, c.Q, LDP, N, K, 0, 0);
+    lds_barrier();
     for (int ks = 0; ks < K32 / 32; ++ks) {
       bf16x8 wf[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wf[t] = w_frag(Wl, N, K, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
+      for (int t = 0; t < 2; ++t) wf[t] = lds_frag(c.Q, LDP, (c.wn + 4 * t) * 16 + c.c16, ks * 32 + 8 * c.g);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         bf16x8 a = lds_frag(c.P, LDP, c.wm * WROWS + rt * 16 + c.c16, ks * 32 + 8 * c.g);
@@ -2593,7 +2623,6 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
     }
     if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
     __syncthreads();                               // P fully read; column accumulators cleared
-    float mean[2][4], rstd[2][4], gam[2][4], bet[2][4];
     if (train) {                                   // batch statistics over the valid rows (biased variance)
       float v[2][4];
 #pragma unroll
@@ -2633,8 +2662,6 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
         if (train) { var = col2[min(f, PW - 1)] / Bf; }
         else { mean[t][i] = prm[J->cls_bn_mean[li] + fc]; var = prm[J->cls_bn_var[li] + fc]; }
         rstd[t][i] = 1.0f / sqrtf(var + 1e-5f);
-        gam[t][i] = prm[J->cls_bn_w[li] + fc];
-        bet[t][i] = prm[J->cls_bn_b[li] + fc];
       }
     if (c.tid < N && train) {                      // per-feature rstd for the backward pass; running statistics
       const float m = col1[c.tid] / Bf, var = col2[c.tid] / Bf;
@@ -2775,6 +2802,14 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
     gcf32 Wl = prm + J->cls_w[li];
     // acc = d h (pre-mask), Q = h of this block.  d y = d h * relu'/dropout mask; BatchNorm backward needs the
     // column sums S1 = sum d y, S2 = sum d y * x_hat
+    float grs[2][4];                               // gamma * rstd of this lane's features: requested before the barriers
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int fc = min((c.wn + 4 * t) * 16 + 4 * c.g + i, N - 1);
+        grs[t][i] = prm[J->cls_bn_w[li] + fc] * W.rstd[li][fc];
+      }
     if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
     __syncthreads();
     float v1[2][4], v2[2][4];
@@ -2811,7 +2846,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
         const int fc = min(f0 + i, N - 1);
         s1[i] = col1[min(f0 + i, PW - 1)] * c.inv_b;
         s2[i] = col2[min(f0 + i, PW - 1)] * c.inv_b;
-        gr_[i] = prm[J->cls_bn_w[li] + fc] * W.rstd[li][fc];
+        gr_[i] = grs[t][i];
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {

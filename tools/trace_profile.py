@@ -12,7 +12,8 @@ TAGS = {0: "enc L0 fwd", 1: "enc hidden fwd", 2: "enc heads", 3: "latent + KL", 
         15: "enc L0 wgrad+adam", 62: "tail", 63: "step barrier",
         20: "pass-1 hand-off", 21: "reg head: layer 1 fwd", 22: "reg head: layers 2-3 + MSE", 23: "reg head: bwd layers 3-2",
         24: "reg head: L1 dgrad + d x_hat", 25: "reg head: L1 wgrad+adam", 26: "cls head: hidden fwd", 27: "cls head: out + CE + hinge",
-        29: "head tail (cls: backward) + hand-off"}
+        29: "head tail (cls: backward) + hand-off", 30: "cls fwd: input save + bias + GEMM", 31: "cls fwd: batch statistics",
+        32: "cls fwd: BN / ReLU / dropout epilogue"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--steps", type=int, default=16)
