@@ -11,7 +11,7 @@ TAGS = {0: "enc L0 fwd", 1: "enc hidden fwd", 2: "enc heads", 3: "latent + KL", 
         11: "dec bwd wgrad+adam", 12: "dz + fusion bwd", 13: "enc bwd heads dgrad+act", 14: "enc bwd heads/hidden wgrad+...",
         15: "enc L0 wgrad+adam", 62: "tail", 63: "step barrier",
         20: "pass-1 hand-off", 21: "reg head: layer 1 fwd", 22: "reg head: layers 2-3 + MSE", 23: "reg head: bwd layers 3-2",
-        24: "reg head: L1 dgrad + d x_hat", 25: "reg head: L1 wgrad+adam", 26: "cls head: hidden fwd", 27: "cls head: out + CE + hinge",
+        24: "reg head: L1 wgrad+adam", 25: "reg head: L1 d x_hat (dgrad)", 26: "cls head: hidden fwd", 27: "cls head: out + CE + hinge",
         29: "head tail (cls: backward) + hand-off", 30: "cls fwd: input save + bias + GEMM", 31: "cls fwd: batch statistics",
         32: "cls fwd: BN / ReLU / dropout epilogue"}
 ap = argparse.ArgumentParser()
