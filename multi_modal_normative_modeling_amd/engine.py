@@ -493,9 +493,10 @@ class JobSet:
 
     def head_regression(self, backward: bool, grads: bool = True, adam: bool = False, step: int = 0, tile0: int = 0,
                         n_tiles: int = 1):
-        """nm_head_regression on the reconstructions a preceding forward() / NM_F_EXPORT launch exported:
-        fills out_fi_pred and loss_log[..][NM_LOSS_REG]; with backward also dloc_extra and the regressor's
-        gradients / Adam update (cVAE.py:2309-2346)."""
+        """nm_head_regression on the residual images a preceding forward() / NM_F_EXPORT launch left in job.reg_resid:
+        fills out_fi_pred and loss_log[..][NM_LOSS_REG]; with backward also job.reg_dres (d MSE / d x_hat, bf16 chunk
+        images) and the regressor's gradients / Adam update (cVAE.py:2309-2346).  Training runs through
+        train_regression (one launch for trunk and head)."""
         ptr = self._upload(max(n_tiles, 1))
         flags = (_lib.NM_F_BACKWARD if backward else 0) | (_lib.NM_F_GRADS if grads and backward else 0) | \
                 (_lib.NM_F_ADAM if adam and backward else 0)
