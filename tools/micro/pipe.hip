@@ -48,20 +48,22 @@ __global__ __launch_bounds__(512) void k_dma(const char* base, int region_kb, in
   sink[blockIdx.x * 512 + t] = acc;
 }
 
-template <int DEPTH, bool NT>
+// IL: p / m / v of a tile adjacent in memory ([tile][3][256 floats]: one 3-KiB burst per tile) instead of three arrays
+template <int DEPTH, bool NT, bool IL = false>
 __global__ __launch_bounds__(512) void k_adam(float* base, int region_kb, int reps, unsigned long long* cyc) {
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   // region = 3 arrays of region_kb/3 KiB; tiles of 1 KiB per array; wave w takes tiles w, w+8, ...
   const int tiles = region_kb / 3;
   GAS float* P = (GAS float*)base + (size_t)blockIdx.x * region_kb * 256;
-  GAS float* M = P + (size_t)tiles * 256;
-  GAS float* V = M + (size_t)tiles * 256;
+  GAS float* M = P + (IL ? (size_t)256 : (size_t)tiles * 256);
+  GAS float* V = M + (IL ? (size_t)256 : (size_t)tiles * 256);
+  constexpr int TS = IL ? 768 : 256;                 // floats between consecutive tiles of one array
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int r = 0; r < reps; ++r) {
     f32x4 p[DEPTH], m[DEPTH], v[DEPTH];
     int tl = wave;
     auto req = [&](int i, int tile) {
-      const size_t o = (size_t)tile * 256 + lane * 4;
+      const size_t o = (size_t)tile * TS + lane * 4;
       if (NT) { p[i] = __builtin_nontemporal_load((const GAS f32x4*)(P + o)); m[i] = __builtin_nontemporal_load((const GAS f32x4*)(M + o)); v[i] = __builtin_nontemporal_load((const GAS f32x4*)(V + o)); }
       else { p[i] = *(const GAS f32x4*)(P + o); m[i] = *(const GAS f32x4*)(M + o); v[i] = *(const GAS f32x4*)(V + o); }
     };
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(512) void k_adam(float* base, int region_kb, int re
         if (cur >= tiles) break;
         const int nx = cur + 8 * (DEPTH - 1);
         if (nx < tiles) req((i + DEPTH - 1) % DEPTH, nx);
-        const size_t o = (size_t)cur * 256 + lane * 4;
+        const size_t o = (size_t)cur * TS + lane * 4;
         f32x4 pp = p[i], mm = m[i], vv = v[i];
         mm = mm * 0.9f + 0.1f; vv = vv * 0.999f + 0.001f; pp = pp - 1e-4f * mm;
         if (NT) { __builtin_nontemporal_store(pp, (GAS f32x4*)(P + o)); __builtin_nontemporal_store(mm, (GAS f32x4*)(M + o)); __builtin_nontemporal_store(vv, (GAS f32x4*)(V + o)); }
@@ -121,6 +123,13 @@ int main() {
       printf("adam  wgs %3d region %4d KiB depth %d nt %d : %6.2f B/clk/CU r+w (%.1f GB/s/CU, %.2f TB/s chip)\n", wgs, rk, D, NT, \
              2.0 * rk * 1024 * reps / med(h, wgs), 2.0 * rk * 1024 * reps / (ms * 1e-3) / 1e9, 2.0 * rk * 1024 * reps * wgs / (ms * 1e-3) / 1e12); }
       RUN_ADAM(1, false) RUN_ADAM(2, false) RUN_ADAM(2, true) RUN_ADAM(4, true) RUN_ADAM(8, true)
+#define RUN_ADAM_IL(D, NT) { \
+      hipLaunchKernelGGL((k_adam<D, NT, true>), dim3(wgs), dim3(512), 0, 0, (float*)buf, rk, reps, cyc); hipDeviceSynchronize(); \
+      hipEventRecord(e0); hipLaunchKernelGGL((k_adam<D, NT, true>), dim3(wgs), dim3(512), 0, 0, (float*)buf, rk, reps, cyc); hipEventRecord(e1); hipDeviceSynchronize(); \
+      float ms; hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, cyc, wgs * 8, hipMemcpyDeviceToHost); \
+      printf("adamIL wgs %3d region %4d KiB depth %d nt %d : %6.2f B/clk/CU r+w (%.1f GB/s/CU, %.2f TB/s chip)\n", wgs, rk, D, NT, \
+             2.0 * rk * 1024 * reps / med(h, wgs), 2.0 * rk * 1024 * reps / (ms * 1e-3) / 1e9, 2.0 * rk * 1024 * reps * wgs / (ms * 1e-3) / 1e12); }
+      RUN_ADAM_IL(1, false) RUN_ADAM_IL(2, false) RUN_ADAM_IL(2, true) RUN_ADAM_IL(4, true)
     }
   }
   return 0;
