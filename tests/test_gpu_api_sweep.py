@@ -452,12 +452,14 @@ def test_fused_endtoend_training_matches_reference_trajectory():
             assert float((sd[k] - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, k
 
 
-def test_classifier_head_config5_shape_vs_oracle():
-    """nm_head_classifier at the config-5 shape (Z = 64, classifier [128, 64, 32], ragged batch of 200): logits,
-    cross entropy, hinge, every gradient of the model (classifier weights / BatchNorm affine, and the trunk
-    gradients that receive d CE / d z and the hinge row coefficients) against the oracle with the kernel's
-    operand rounding; eval-mode predict() against the oracle with running statistics."""
-    dims, hidden, Z, cdim, B, layers = [60, 45, 70], [40, 32], 64, 5, 200, [128, 64, 32]
+@pytest.mark.parametrize("dims,hidden,cdim,B", [([60, 45, 70], [40, 32], 5, 200), ([379, 379, 379], [110, 110], 29, 256)])
+def test_classifier_head_config5_shape_vs_oracle(dims, hidden, cdim, B):
+    """The end-to-end model with the config-5 head (Z = 64, classifier [128, 64, 32]) at a small trunk with a ragged batch
+    of 200 and at BASELINE config 5's full shape (3 x 379 ROI, H = [110, 110], c = 29, batch 256): logits, cross entropy,
+    hinge, every gradient of the model (classifier weights / BatchNorm affine, and the trunk gradients that receive
+    d CE / d z and the hinge row coefficients) against the oracle with the kernel's operand rounding; eval-mode
+    predict() against the oracle with running statistics."""
+    Z, layers = 64, [128, 64, 32]
     torch.manual_seed(9)
     model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
                                         dropout_rate=0.0, num_classes=2)
