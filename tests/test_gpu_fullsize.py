@@ -323,3 +323,76 @@ def test_deviation_pass_at_size_vs_oracle(D, N):
     assert bool((job.out_sqerr[0].cpu()[N:] == 0.0).all())
     if table.x_pitch > D:
         assert bool((job.out_sqerr[0].storage_offset() == 0))
+
+
+@pytest.mark.parametrize("kind", ["regression", "endtoend"])
+def test_head_models_one_launch_full_size_trajectory_vs_oracle(kind):
+    """nm_train_steps_head at BASELINE sizes (3 x 379 ROI, H = [110, 110]; regression: Z = 10, two raw covariates;
+    end-to-end = config 5: Z = 64, 29 covariates, classifier [128, 64, 32], dropout 0): three Adam steps inside ONE launch
+    on three different batches with injected draws, against the oracle stepping with the same batches in bf16-operand
+    mode: the head's loss per step, and every parameter after the third step within the Adam trajectory bound
+    2 lr steps (an isolated ReLU-mask flip moves a parameter by at most one update)."""
+    import multi_modal_normative_modeling_amd as nm
+    steps, B, lr = 3, 256, 1e-4
+    dims, hidden = [379, 379, 379], [110, 110]
+    Z, cdim = (10, 2) if kind == "regression" else (64, 29)
+    layers = [128, 64, 32]
+    g = torch.Generator().manual_seed(77)
+    xes = [torch.randn(steps * B, d, generator=g) for d in dims]
+    c = torch.rand(steps * B, cdim, generator=g)
+    eps = torch.randn(steps, B, Z, generator=g)
+    fi = torch.randn(steps * B, generator=g) * 0.5 + 1.0
+    labels = (torch.rand(steps * B, generator=g) < 0.4).long()
+    torch.manual_seed(3)
+    if kind == "regression":
+        model = nm.cVAE_multimodal_regression(dims, hidden, Z, cdim, learning_rate=lr, modalities=3, non_linear=True)
+        spec = nm.ModelSpec(dims, hidden, Z, cdim, True, "regression")
+        rs = R.Spec(dims, hidden, Z, cdim, True, kind="regression")
+    else:
+        model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
+                                            dropout_rate=0.0, num_classes=2)
+        spec = nm.ModelSpec(dims, hidden, Z, cdim, True, "endtoend", tuple(layers), 2)
+        rs = R.Spec(dims, hidden, Z, cdim, True, kind="endtoend", classifier_layers=layers)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith("num_batches_tracked")}
+    tables = [nm.Table(x, c, DEV) for x in xes]                      # 3 tiles of 256 rows: step s trains on tile s
+    if kind == "regression":
+        job = nm.Job(spec, tables, combine="gpoe", state=sd0, lr=lr, loss_cap=8)
+        job.set_fi(fi)
+    else:
+        job = nm.Job(spec, tables, combine="poe", state=sd0, lr=lr, kl_weight=0.1, ll_weight=0.1, loss_cap=8, single_bypass=False)
+        job.cls_margin, job.cls_w_contrast, job.cls_dropout = 0.5, 0.7, 0.0
+        job.set_labels(labels)
+    job.set_eps(eps)
+    js = nm.JobSet([job])
+    (js.train_regression if kind == "regression" else js.train_endtoend)(steps)
+    torch.cuda.synchronize()
+    got_loss = job.loss_log[:steps].cpu()
+    # oracle: the same three steps
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd0.items()}
+    names = [k for k, v in P.items() if v.requires_grad]
+    opt = R.Adam(P, names, lr=lr)
+    R.set_operand_rounding("bf16")
+    try:
+        for s in range(steps):
+            sl = slice(s * B, (s + 1) * B)
+            xb, cb = [x[sl] for x in xes], [c[sl]] * 3
+            for v in P.values():
+                v.grad = None
+            if kind == "regression":
+                fw = R.forward_regression(P, rs, xb, cb, "gpoe", eps[s])
+                lo = R.loss_regression(rs, xb, fw, fi[sl].reshape(-1, 1), lambda_reg=1.0)
+                lo["total"].backward()
+                ref_head = float(lo["regression"])
+                assert abs(float(got_loss[s, 12]) - ref_head) <= 2e-2 * abs(ref_head) + 1e-4, (s, float(got_loss[s, 12]), ref_head)
+            else:
+                fw = R.forward_endtoend(P, rs, xb, cb, eps[s], training=True)
+                lo = R.loss_endtoend(rs, xb, fw, labels[sl], margin=0.5, weightcontrastive=0.7)
+                lo["total_loss"].backward()
+                ref_head = float(lo["classification_loss"])
+                assert abs(float(got_loss[s, 13]) - ref_head) <= 2e-2 * abs(ref_head) + 1e-4, (s, float(got_loss[s, 13]), ref_head)
+            opt.step(P, {n: P[n].grad for n in names})
+    finally:
+        R.set_operand_rounding("fp32")
+    sd = job.state_dict()
+    worst = max((float((sd[k] - P[k].detach()).abs().max()), k) for k in names)
+    assert worst[0] <= 2.0 * lr * steps + 1e-6, worst
