@@ -56,7 +56,9 @@ enum {
   NM_F_ZGIVEN   = 32,  /* job.eps holds the latent z itself: decode(z, c, m), cVAE.py:1135 */
   NM_F_TRACE    = 64,  /* workgroup (0,0): per-wave interval timers between in-kernel stamps */
   NM_F_BNSTATS  = 256, /* nm_head_classifier: update BatchNorm running statistics (once per train-mode forward) */
-  NM_F_SPLIT    = 512  /* set by nm_launch_split: one workgroup per (job, modality) */
+  NM_F_SPLIT    = 512, /* set by nm_launch_split: one workgroup per (job, modality) */
+  NM_F_FAULT_INJECT = 1024 /* diagnostic, nm_launch_split only: part 1 of every job leaves at once, so the others' hand-off
+                              times out (test of the error path: nm_split_errors) */
 };
 
 /* One modality (expert) of a model: its ROI table and where its tensors live inside the
@@ -237,6 +239,11 @@ int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_til
  * bit-identical to nm_launch.  Status -16: ceil(n_jobs / 8) * 8 * parts exceeds the CU count (the parts wait for each
  * other inside the launch, so all of them must be resident). */
 int nm_launch_split(const nm_job_t* jobs_dev, int n_jobs, int parts, int step0, int n_steps, int flags, void* stream);
+/* out_dev[j] (device, n_jobs ints) != 0: a hand-off of job j timed out in a split launch since the word was last
+ * cleared -- its workgroups left the launch at that point and its parameters / moments are not to be trusted (the
+ * launch itself still returns 0: the kernel cannot fail the stream).  clear != 0 zeroes the words after reading.
+ * The reference has no counterpart (single process, single model: cVAE.py:1166-1196). */
+int nm_split_errors(const nm_job_t* jobs_dev, int n_jobs, int* out_dev, int clear, void* stream);
 
 /* Convenience wrappers over nm_launch (same status convention). */
 int nm_train_steps(const nm_job_t* jobs_dev, int n_jobs, int step0, int n_steps, void* stream);

@@ -34,6 +34,7 @@ NM_LOSS_CE = 13
 NM_LOSS_CONTRAST = 14
 NM_F_BNSTATS = 256
 NM_F_SPLIT = 512
+NM_F_FAULT_INJECT = 1024
 NM_METRICS_MAX_N = 8192
 NM_METRICS_STRIDE = 8
 
@@ -120,6 +121,7 @@ def load():
     for name in ("nm_launch", "nm_launch_scalar_tr"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_launch_split.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.nm_split_errors.argtypes = [vp, i32, vp, i32, vp]
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_train_steps_persistent.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_deviation.argtypes = [vp, i32, i32, i32, vp]
@@ -153,7 +155,7 @@ EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_wgtimes_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
-    "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split",
+    "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split", "nm_split_errors",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
 ]
 

@@ -5,21 +5,20 @@
 // MLPs -> Gaussian NLL + KL -> backward -> Adam, with no inter-workgroup communication.  The
 // sweep fills the chip with independent jobs (one workgroup per CU), see DESIGN.md.
 //
-// Data placement per workgroup
+// Data placement per workgroup (DESIGN.md section 3)
 //   LDS  P [256][136] bf16 : the running activation / delta of the layer chain (updated in place)
-//        Q [256][136] bf16 : the other operand of the current layer (saved activation, staged
-//                            x-chunk, or delta chunk of the decoder output layer)
-//        S [4352] fp32     : staging slab of a weight-gradient tile group for the coalesced Adam sweep
-//   HBM/L2  fp32 parameters + Adam moments in the reference's own tensor layout.  Weights are read
-//           straight into MFMA fragments (fp32 -> bf16 in registers), each element once per pass;
-//           Adam streams p/m/v as contiguous 16-byte-per-lane sweeps over each gradient slab.
-//   workspace (L2-resident): fp32 latent statistics, bf16 activations saved for backward.
+//        Q [256][136] bf16 : two [128][136] weight-image halves, or a saved activation, or x-chunk stages, or the
+//                            delta chunk + an output-chunk slot + transposition patches of the decoder output layer
+//        S 18 KiB          : the other output-chunk slot / overflow of the second x stage + patches
+//   HBM  fp32 parameters + Adam moments as 16 x 16 tiles (1 KiB each, lane-linear in the Adam units);
+//        bf16 shadow images of every weight matrix in exactly the LDS layout (LDS-DMA copies, requested one phase
+//        ahead); workspace: fp32 latent statistics, bf16 activation images saved for the backward pass.
 //
 // Every contraction is a v_mfma_f32_16x16x32_bf16 (fp32 accumulate), issued "transposed":
 // the FEATURE index of the result lives in the accumulator registers (4 consecutive features per
 // lane) and the batch ROW on the lane, so every epilogue touches 8 or 16 contiguous bytes:
-//   forward  out[r][n] = sum_k P[r][k] W[n][k]      A = W rows (global),   B = ds_read_b128 of P rows
-//   dgrad    din[r][k] = sum_n P[r][n] W[n][k]      A = W columns (global), B = ds_read_b128 of P rows
+//   forward  out[r][n] = sum_k P[r][k] W[n][k]      A = ds_read_b128 of the weight image, B = ds_read_b128 of P rows
+//   dgrad    din[r][k] = sum_n P[r][n] W[n][k]      A = the same image through ds_read_b64_tr_b16, B = P rows
 //   wgrad    dW[n][k]  = sum_r P[r][n] Q[r][k]      A, B = ds_read_b64_tr_b16 (transposing LDS read)
 //
 // Reference semantics restated here (paths relative to the reference checkout):
@@ -56,8 +55,7 @@ constexpr int OCH = 64;                              // ROI columns per output c
 constexpr int OIMG_BYTES = OCH * LDP * 2;            // 17,408: [64][136] rows of decoder_mean_layer
 constexpr int OBLOB_BYTES = 18432;                   // image + bias[64] + logvar_out[64] (fp32), padded to 18 pieces
 constexpr int ACT_BYTES = ROWS * LDP * 2;            // 69,632: a saved activation in LDS layout
-constexpr int PATCH_LD = 20;                         // floats: 16 + 4 (conflict-free 16-byte patch writes)
-constexpr int PATCH_FLOATS = 16 * PATCH_LD;          // one wave's 16 x 16 fp32 transposition patch
+constexpr int PATCH_FLOATS = 16 * 16;                // one wave's 16 x 16 fp32 transposition patch (block-swizzled, see wgrad_adam)
 constexpr int SPATCH_OFF = 8192;                     // patches inside S (bytes): above the 4 KiB the second x slot runs into S
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
@@ -96,6 +94,8 @@ struct Ctx {
   float* colacc;     // [128] per-column accumulators
   float* rowacc;     // [256] per-row accumulators
   float* lse;        // [256] logsumexp over the rows of every expert's mu column (mvtCAE total correlation)
+  float* bgrad;      // [128] bias gradients of the current weight-gradient pass (the ones column), see wgrad_adam
+  unsigned* abort;   // [1] set by split_handoff on a time-out: the workgroup leaves the launch
   unsigned long long* tlast;   // [8] last stamp per wave (NM_F_TRACE)
   int tid, lane, wave, wm, wn, g, c16;
   int row0;          // first table row of this tile
@@ -121,6 +121,7 @@ struct WsLayout {
   int Zs;
 };
 constexpr int WS_SYNC_BYTES = 256;       // hand-off counters of the split mode: A at +0, B at +64, error flag at +128
+constexpr int WS_SYNC_ERR_WORD = 32;
 __host__ __device__ inline WsLayout ws_layout(int M, int L, int Z) {
   WsLayout w;
   w.Zs = rup(Z, 16);
@@ -372,22 +373,6 @@ __device__ __forceinline__ void apply_grad(const Ctx& c, int64_t idx, float g, G
 // activations) is therefore kept in global memory in exactly the LDS layout, in 1-KiB pieces, and is requested
 // one phase ahead of its use.
 typedef __attribute__((address_space(3))) void* lds_vp;
-#ifndef NM_NT_STREAM
-#define NM_NT_STREAM 0
-#endif
-// Requesting the p / m / v of a weight-gradient phase's first units one or more phases ahead (output chunks: before the
-// GEMM / after the epilogue; hidden layers: before the dgrad; first encoder layer: a whole pass ahead).  Measured
-// (round 2, 256 SE-gPoE models): every variant costs registers the step does not have -- 18 to 227 VGPR spills --
-// and is 0 % (hidden) to 13 % (output chunks, first layer) SLOWER.  Kept as compile-time experiments, off.
-#ifndef NM_PRE_OUT
-#define NM_PRE_OUT 0
-#endif
-#ifndef NM_PRE_HID
-#define NM_PRE_HID 0
-#endif
-#ifndef NM_PRE_L0
-#define NM_PRE_L0 0
-#endif
 // POL = 2: streaming (nt) -- for bytes this workgroup alone reads, once per step (weight images, saved activations);
 // the ROI tables, which the models of a fold share through L2 / Infinity Cache, keep the default policy.
 template <int POL = 0>
@@ -396,7 +381,7 @@ __device__ __forceinline__ void dma16(const GAS char* src_lane, char* dst_wave) 
 }
 // pieces [0, npieces) of 1 KiB, contiguous on both sides; wave w takes w, w + 8, ...  Returns the number of
 // instructions THIS wave issued (wave-uniform): the count a later s_waitcnt vmcnt(N) needs.
-template <int POL = (NM_NT_STREAM ? 2 : 0)>
+template <int POL = 0>
 __device__ __forceinline__ int dma_lin(const Ctx& c, const GAS char* src, char* dst, int npieces) {
   int n = 0;
   for (int p = c.wave; p < npieces; p += NWAVES) {
@@ -436,8 +421,10 @@ __device__ __forceinline__ void handoff_barrier() {
 // its stores are globally visible, and leaves once all parts of the job have arrived.  Form: every wave drains its
 // own stores, the workgroup meets, one lane releases at agent scope (write-back of this XCD's L2), adds its arrival,
 // polls relaxed, acquires at agent scope (this CU's L1 is invalidated) -- MI355X_MICROARCH.md, "Valid forms".
-// The spin is bounded: on a time-out the error word is set and the step goes on (the host checks it).
-__device__ __forceinline__ void split_handoff(const Ctx& c, GAS unsigned* cnt, GAS unsigned* err, unsigned target) {
+// The spin is bounded (~1 s): on a time-out the job's error word (workspace + 128, sticky: nm_split_errors reads it,
+// only the host clears it) is set and the workgroup LEAVES the launch -- the other parts' statistics are stale, so
+// nothing computed from them may reach the parameters.  Returns false in that case (for every thread).
+__device__ __forceinline__ bool split_handoff(const Ctx& c, GAS unsigned* cnt, GAS unsigned* err, unsigned target) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (c.tid == 0) {
@@ -445,15 +432,23 @@ __device__ __forceinline__ void split_handoff(const Ctx& c, GAS unsigned* cnt, G
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add((unsigned*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
+    bool ok = true;
     while (__hip_atomic_load((unsigned*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++spins > (1 << 22)) { __hip_atomic_store((unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      // (another part that has already given up also ends this wait: no part is left spinning for its full bound)
+      if (++spins > (1 << 22) || __hip_atomic_load((unsigned*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store((unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *c.abort = ok ? 0u : 1u;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  return *c.abort == 0u;
 }
 
 // What a GEMM phase requests for the phase after it: `np` 1-KiB pieces src -> dst and, optionally, one more piece
@@ -466,7 +461,7 @@ __device__ __forceinline__ Next no_next() { return Next{nullptr, nullptr, 0, nul
 __device__ __forceinline__ int issue_next(const Ctx& c, const Next& nx) {
   int n = 0;
   if (nx.src) n = dma_lin(c, nx.src, nx.dst, nx.np);
-  if (nx.vsrc && c.wave == 2) { dma16<(NM_NT_STREAM ? 2 : 0)>(nx.vsrc + (c.lane << 4), nx.vdst); ++n; }
+  if (nx.vsrc && c.wave == 2) { dma16<0>(nx.vsrc + (c.lane << 4), nx.vdst); ++n; }
   return n;
 }
 // a [128][136] weight image + its vector piece into half `half` of Q / vector slot `half`
@@ -482,11 +477,7 @@ __device__ __forceinline__ void store_act_img(const Ctx& c, gbf16 dst, const __b
   for (int i = 0; i < (ROWS * 16) / WG; ++i) {
     const int p = c.tid + i * WG, row = p >> 4, seg = p & 15;
     const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * LDP + seg * 8);
-#if NM_NT_STREAM
-    __builtin_nontemporal_store(v, (GAS u32x4*)(dst + row * LDP + seg * 8));
-#else
     *(GAS u32x4*)(dst + row * LDP + seg * 8) = v;
-#endif
   }
 }
 // legacy [256][PW] workspace tiles (head kernels, fusion-backward hand-off)
@@ -694,7 +685,7 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const GAS char* x
   };
   int n_nxt = 0, n_blob = 0;
   issue_chunk(0);
-  if (c.wave == 3) dma16<(NM_NT_STREAM ? 2 : 0)>(wsrc + (int64_t)nch * W0IMG_BYTES + (c.lane << 4), reinterpret_cast<char*>(bias));
+  if (c.wave == 3) dma16<0>(wsrc + (int64_t)nch * W0IMG_BYTES + (c.lane << 4), reinterpret_cast<char*>(bias));
   if (nch > 1) n_nxt = issue_chunk(1);
   else n_blob = issue_next(c, nx);
   f32x4 acc[2][RT];
@@ -868,14 +859,25 @@ __device__ __forceinline__ void finish_delta(const Ctx& cc, const f32x4 (&acc)[2
 // k = k_base + kk (k_base a multiple of 16); k < K is W[n][k], k == K the bias b[n] (ones column), beyond: nothing.
 // A unit = one 16-row n tile x two adjacent 16-column k tiles (the n-side fragment is shared).  The waves take
 // units round-robin and run them INDEPENDENTLY -- no workgroup barrier, no shared slab: per unit a wave
-//   (i)   has already requested p / m / v of its NEXT unit: the master keeps every 16 x 16 tile as 1 KiB of
-//         contiguous memory, so each request is one lane-linear 16-byte load per lane (full lines, streaming);
+//   (i)   requests p / m / v of its NEXT unit: the master keeps every 16 x 16 tile as 1 KiB of contiguous memory,
+//         so each request is one lane-linear 16-byte load per lane (full lines, streaming);
 //   (ii)  runs the unit's MFMAs through the transposing LDS reads;
 //   (iii) turns each accumulator tile (lane = row n, 4 consecutive k) into the master's lane order through a
 //         private 16 x 16 fp32 LDS patch (the LDS traffic of one wave is in order: no barrier);
 //   (iv)  applies Adam, stores p / m / v lane-linear again and the new weights as bf16 into the shadow image.
 // While one wave waits for its moments the others are in their MFMA loops.  One barrier at the end (the caller
-// may overwrite the operands).
+// may overwrite the operands), then the bias vector (its gradient = the ones column, parked in LDS by the unit
+// that owns it) is updated by one thread per row.
+//
+// The p / m / v requests are hand-issued (inline asm) and hand-waited: the compiler's own s_waitcnt placement
+// cannot count vector-memory operations across the wave-uniform branches of the unit loop (tile validity, shadow,
+// gradient export) and falls back to vmcnt(0) at every use -- which waited for the NEXT unit's requests and for the
+// previous tile's store acknowledgements, i.e. two exposed memory round trips per unit (round 2: 12.6 B/clk per CU
+// in these phases on an EMPTY chip).  Here every request is unconditional (out-of-range tiles read a clamped
+// address and are not stored), so a wave knows how many operations are younger than the set it is about to use:
+// 6 requests of the next unit + the stores of the previous one, which may all stay in flight.  Two register sets
+// (A / B) swap roles from unit to unit; the loop is unrolled by two so that no set is ever copied while its loads
+// are in flight.
 struct WgT {
   int64_t w_off;      // master offset of tile (0, 0) of this row block
   int64_t b_off;      // master offset of the bias of row 0 (< 0: the pass has no bias column)
@@ -885,48 +887,28 @@ struct WgT {
   float* patch;       // LDS, NWAVES * PATCH_FLOATS floats
 };
 struct WgGeom { int N, K, k_base, ncols; WgT T; };
-struct PMV { f32x4 p[2], m[2], v[2]; float bp, bm, bv; };
+struct PMV { f32x4 p0, m0, v0, p1, m1, v1; };
 __device__ __forceinline__ int wg_units(const WgGeom& G) { return ((G.N + 15) >> 4) * ((((G.ncols + 15) >> 4) + 1) >> 1); }
 __device__ __forceinline__ int wg_bias_pair(const WgGeom& G) {
   const bool has_bias = (G.T.b_off >= 0) && (G.K >= G.k_base) && (G.K < G.k_base + G.ncols);
   return has_bias ? ((G.K - G.k_base) >> 5) : -1;
 }
-// Request p / m / v of unit u (wave-uniform) of geometry G: the master keeps every 16 x 16 tile as 1 KiB of
-// contiguous memory, so each request is one lane-linear 16-byte load per lane (full lines, streaming).
-__device__ __forceinline__ void wg_request(const Ctx& c, const WgGeom& G, int u, PMV& s) {
-  const nm_job_t* J = c.job;
-  gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
-  const int KT = ktiles(G.K), kt0 = G.k_base >> 4;
-  const int nktp = (G.ncols + 15) >> 4, nkp = (nktp + 1) >> 1;
-  const int nt = u / nkp, kp = u - nt * nkp;            // wave-uniform: scalar division
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ktl = 2 * kp + j;
-    s.p[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s.m[j] = s.p[j]; s.v[j] = s.p[j];
-    if (ktl < nktp && kt0 + ktl < KT) {
-      const int64_t idx = G.T.w_off + ((int64_t)(nt * KT + kt0 + ktl) << 8) + c.lane * 4;
-#if NM_NT_STREAM
-      s.p[j] = __builtin_nontemporal_load((const GAS f32x4*)(Pp + idx));
-#else
-      s.p[j] = *(const GAS f32x4*)(Pp + idx);
-#endif
-      // the moments are touched once per step: streaming (nt) accesses keep them from evicting what is re-read
-      s.m[j] = __builtin_nontemporal_load((const GAS f32x4*)(Mp + idx));
-      s.v[j] = __builtin_nontemporal_load((const GAS f32x4*)(Vp + idx));
-    }
-  }
-  s.bp = 0.f; s.bm = 0.f; s.bv = 0.f;
-  if (kp == wg_bias_pair(G)) {
-    const int64_t bidx = G.T.b_off + min(nt * 16 + (c.lane >> 2), G.N - 1);
-    s.bp = Pp[bidx]; s.bm = Mp[bidx]; s.bv = Vp[bidx];
-  }
-}
+// 16 bytes per lane from (wave-uniform 64-bit base in SGPRs) + (32-bit byte offset per lane); NT: streaming policy
+// (the moments are touched once per step: they should not evict what is re-read).  "+v": the destination is tied, so
+// the register allocator never has a reason to move the value between the request and the wait.
+#define NM_GLOAD16(dst, voff, sbase) \
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#define NM_GLOAD16_NT(dst, voff, sbase) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#define NM_GLOAD4(dst, voff, sbase) \
+  asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory")
+constexpr int WG_LOADS = 6;      // vector-memory operations of one wg_issue
 
-// pre0 / pre1: p / m / v of this wave's first / second unit (units wave, wave + 8), requested by the caller phases
-// ahead (nullptr: requested here).
+// Returns a LOWER bound of the vector-memory operations this wave issued here (for the caller's counted waits on
+// copies it requested before the call).
 template <bool SCALAR_TR>
-__device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
-                                           const WgGeom& G, const PMV* pre0 = nullptr, const PMV* pre1 = nullptr) {
+__device__ __forceinline__ int wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
+                                          const WgGeom& G) {
   Ctx c = cc;
   relaunder(c);
   const nm_job_t* J = c.job;
@@ -944,21 +926,41 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
   gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
   float* patch = T.patch + c.wave * PATCH_FLOATS;
   const int prow = c.lane >> 2, pcol = (c.lane & 3) * 4;          // this lane's element group inside a tile
+  // patch swizzle: 16-byte block b of row r sits at block b ^ ((r >> 1) & 3) -- the accumulator write (lane = row,
+  // block = lane group) and the master-order read (lane = 4 row + block) are both conflict-free
+  float* const pw = patch + c.c16 * 16 + 4 * (c.g ^ ((c.c16 >> 1) & 3));
+  const float* const pr = patch + prow * 16 + 4 * ((c.lane & 3) ^ ((prow >> 1) & 3));
+  const float* const pb = patch + prow * 16 + 4 * ((kb_col >> 2) ^ ((prow >> 1) & 3)) + (kb_col & 3);
+  const unsigned lane16 = (unsigned)c.lane << 4;
 
-  PMV cur, nxt;
-  int u = c.wave;
-  bool have_nxt = false;
-  if (do_adam && u < nunits) {
-    if (pre0) cur = *pre0; else wg_request(c, G, u, cur);
-    if (pre1 && u + NWAVES < nunits) { nxt = *pre1; have_nxt = true; }
+  // the bias rows' p / m / v (waves 0 and 1, one row per lane): requested first, used after the unit loop
+  const bool bias_wave = kb_pair >= 0 && do_adam && c.wave < 2;
+  float bp, bm, bv;
+  asm volatile("" : "=v"(bp), "=v"(bm), "=v"(bv));
+  if (bias_wave) {
+    const unsigned boff = (unsigned)(T.b_off + min(c.tid, N - 1)) << 2;
+    NM_GLOAD4(bp, boff, Pp); NM_GLOAD4(bm, boff, Mp); NM_GLOAD4(bv, boff, Vp);
   }
-  while (u < nunits) {
-    const int un = u + NWAVES;
-    if (do_adam && !have_nxt && un < nunits) wg_request(c, G, un, nxt);
-    have_nxt = false;
+  int young = 0;                                 // this wave's vector-memory operations since the bias request (capped)
+
+  // request p / m / v of both tiles of unit u (wave-uniform) into set s: always WG_LOADS operations
+  auto issue = [&](int u, PMV& s) {
+    const int nt = u / nkp, kp = u - nt * nkp;            // wave-uniform: scalar division
+    const int t0 = min(kt0 + 2 * kp, KT - 1), t1 = min(kt0 + 2 * kp + 1, KT - 1);
+    const unsigned o0 = (unsigned)((T.w_off + ((int64_t)(nt * KT + t0) << 8)) << 2) + lane16;
+    const unsigned o1 = (unsigned)((T.w_off + ((int64_t)(nt * KT + t1) << 8)) << 2) + lane16;
+    NM_GLOAD16(s.p0, o0, Pp); NM_GLOAD16_NT(s.m0, o0, Mp); NM_GLOAD16_NT(s.v0, o0, Vp);
+    NM_GLOAD16(s.p1, o1, Pp); NM_GLOAD16_NT(s.m1, o1, Mp); NM_GLOAD16_NT(s.v1, o1, Vp);
+  };
+  // set s is complete once at most `younger` of this wave's vector-memory operations are outstanding
+  auto wait_set = [&](PMV& s, int younger) {
+    wait_vm(younger);
+    asm volatile("" : "+v"(s.p0), "+v"(s.m0), "+v"(s.v0), "+v"(s.p1), "+v"(s.m1), "+v"(s.v1));
+  };
+  // MFMAs of unit u: acc[j] = k tile 2 kp + j of n tile nt
+  auto unit_mfma = [&](int u, f32x4 (&acc)[2]) {
     const int nt = u / nkp, kp = u - nt * nkp;
-    // ---- MFMAs: acc[j] = k tile 2 kp + j of n tile nt ----
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
     const int ncol0 = a_col0 + nt * 16;
     if (SCALAR_TR) {
       for (int rs = 0; rs < ROWS / 32; ++rs) {
@@ -994,62 +996,92 @@ __device__ __forceinline__ void wgrad_adam(const Ctx& cc, const __bf16* A, int l
         na += 2 * n_step; ka += 2 * k_step;
       }
     }
-    // ---- per tile: accumulators -> master lane order -> Adam ----
-    // MFMA lane (c16, g) holds dW[n = nt*16 + c16][kk = ktl*16 + 4g .. +3]; master lane L holds row L / 4,
-    // columns 4 (L % 4) .. +3 of the tile.
+  };
+  // Per tile: accumulators -> master lane order -> Adam -> stores.  MFMA lane (c16, g) holds
+  // dW[n = nt*16 + c16][kk = ktl*16 + 4g .. +3]; master lane L holds row L / 4, columns 4 (L % 4) .. +3 of the tile.
+  // Returns the number of vector-memory stores this wave issued (wave-uniform).
+  auto finish_unit = [&](int u, PMV& s, const f32x4 (&acc)[2]) {
+    const int nt = u / nkp, kp = u - nt * nkp;
     const int n = nt * 16 + prow;
+    int nst = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ktl = 2 * kp + j;
-      *reinterpret_cast<f32x4*>(patch + c.c16 * PATCH_LD + 4 * c.g) = acc[j];
-      f32x4 g = *reinterpret_cast<const f32x4*>(patch + prow * PATCH_LD + pcol);
-      const float bg = patch[prow * PATCH_LD + kb_col];
+      *reinterpret_cast<f32x4*>(pw) = acc[j];
+      f32x4 g = *reinterpret_cast<const f32x4*>(pr);
+      const float bg = *pb;
       const int k0 = k_base + ktl * 16 + pcol;
+      if (nt * 16 + 16 > N || k_base + ktl * 16 + 16 > K) {      // wave-uniform: an edge tile -- pad rows / columns keep zero gradient
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = (n < N && k0 + i < K) ? g[i] : 0.f;          // pad rows / columns keep zero gradient
+        for (int i = 0; i < 4; ++i) g[i] = (n < N && k0 + i < K) ? g[i] : 0.f;
+      }
       if (ktl < nktp && kt0 + ktl < KT) {                                            // wave-uniform
         const int64_t idx = T.w_off + ((int64_t)(nt * KT + kt0 + ktl) << 8) + c.lane * 4;
-        if (do_grads) *(GAS f32x4*)(asg(J->grads) + idx) = g;
+        if (do_grads) { *(GAS f32x4*)(asg(J->grads) + idx) = g; ++nst; }
         if (do_adam) {
-          f32x4 p4 = cur.p[j], m4 = cur.m[j], v4 = cur.v[j];
+          f32x4 p4 = j ? s.p1 : s.p0, m4 = j ? s.m1 : s.m0, v4 = j ? s.v1 : s.v0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) { float pp = p4[i], mm = m4[i], v2 = v4[i]; adam1(ak, g[i], pp, mm, v2); p4[i] = pp; m4[i] = mm; v4[i] = v2; }
-#if NM_NT_STREAM
-          __builtin_nontemporal_store(p4, (GAS f32x4*)(Pp + idx));
-#else
           *(GAS f32x4*)(Pp + idx) = p4;
-#endif
           __builtin_nontemporal_store(m4, (GAS f32x4*)(Mp + idx));
           __builtin_nontemporal_store(v4, (GAS f32x4*)(Vp + idx));
+          nst += 3;
           if (T.sh) {
             bf16x4 pk;
 #pragma unroll
             for (int i = 0; i < 4; ++i) pk[i] = (__bf16)p4[i];
-#if NM_NT_STREAM
-            __builtin_nontemporal_store(pk, (GAS bf16x4*)(T.sh + (int64_t)n * T.sh_pitch + (ktl * 16 + pcol) * 2));
-#else
             *(GAS bf16x4*)(T.sh + (int64_t)n * T.sh_pitch + (ktl * 16 + pcol) * 2) = pk;
-#endif
+            ++nst;
           }
         }
       }
       if (kp == kb_pair && j == kb_j) {              // wave-uniform: this tile carries the ones column
-        if (pcol == 0 && n < N) {                    // one lane per row
-          const int64_t bidx = T.b_off + n;
-          if (do_grads) asg(J->grads)[bidx] = bg;
-          if (do_adam) {
-            float bp = cur.bp, bm = cur.bm, bv = cur.bv;
-            adam1(ak, bg, bp, bm, bv);
-            Pp[bidx] = bp; Mp[bidx] = bm; Vp[bidx] = bv;
-            if (T.sh_b) T.sh_b[n] = bp;
-          }
-        }
+        if (pcol == 0 && n < N) c.bgrad[n] = bg;     // one lane per row; consumed after the barrier below
       }
     }
-    cur = nxt;
-    u = un;
+    return nst;
+  };
+
+  PMV sa, sb;
+  asm volatile("" : "=v"(sa.p0), "=v"(sa.m0), "=v"(sa.v0), "=v"(sa.p1), "=v"(sa.m1), "=v"(sa.v1));
+  asm volatile("" : "=v"(sb.p0), "=v"(sb.m0), "=v"(sb.v0), "=v"(sb.p1), "=v"(sb.m1), "=v"(sb.v1));
+  int u = c.wave, st_prev = 0;
+  if (do_adam && u < nunits) { issue(u, sa); young += WG_LOADS; }
+  while (u < nunits) {
+    f32x4 acc[2];
+    const int u1 = u + NWAVES, u2 = u + 2 * NWAVES;
+    const bool h1 = do_adam && u1 < nunits;
+    if (h1) { issue(u1, sb); young += WG_LOADS; }
+    unit_mfma(u, acc);
+    if (do_adam) wait_set(sa, st_prev + (h1 ? WG_LOADS : 0));
+    st_prev = finish_unit(u, sa, acc);
+    young += st_prev;
+    if (u1 >= nunits) break;
+    const bool h2 = do_adam && u2 < nunits;
+    if (h2) { issue(u2, sa); young += WG_LOADS; }
+    unit_mfma(u1, acc);
+    if (do_adam) wait_set(sb, st_prev + (h2 ? WG_LOADS : 0));
+    st_prev = finish_unit(u1, sb, acc);
+    young += st_prev;
+    u = u2;
   }
-  lds_barrier();                                    // every wave has finished reading A / B
+  lds_barrier();                                    // every wave has finished reading A / B; the bias gradients are parked
+  if (kb_pair >= 0 && c.wave < 2) {                 // wave-uniform
+    relaunder(c);
+    if (bias_wave) { wait_vm(min(young, 20)); asm volatile("" : "+v"(bp), "+v"(bm), "+v"(bv)); }
+    const int n = c.tid;
+    if (n < N) {
+      const float bg = c.bgrad[n];
+      const int64_t bidx = T.b_off + n;
+      if (do_grads) asg(J->grads)[bidx] = bg;
+      if (do_adam) {
+        adam1(ak, bg, bp, bm, bv);
+        Pp[bidx] = bp; Mp[bidx] = bm; Vp[bidx] = bv;
+        if (T.sh_b) T.sh_b[n] = bp;
+      }
+    }
+  }
+  return young;
 }
 
 // ---- expert fusion (cVAE.py:1144-1164) on one (row, z) element --------------------------------
@@ -1209,11 +1241,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   const float rZc = Zc > 0 ? 1.0f / (float)Zc : 0.f;
   // latent phases four columns at a time when the rows divide evenly (measured: with Z = 10 the 12-column groups
   // leave half the threads a second, mostly padded round -- slower than the element loop; Z = 64: 2.5x faster)
-#ifdef NM_VEC4_ALWAYS
-  const bool vec4 = S == 0;
-#else
   const bool vec4 = S == 0 && (Z & 3) == 0;
-#endif
   const bool sigm = J->out_kind == 1;           // sigmoid output, ll = -0.5 sum (x - x_hat)^2
   gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m + (int64_t)(step & 1) * M * wl.lat);
   gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m + (int64_t)(step & 1) * M * wl.lat);
@@ -1260,7 +1288,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 
   // ================= fusion + reparameterisation + KL =================
   // the heads' mu / logvar stores are complete (split: of every part, made visible across workgroups)
-  if (split) split_handoff(c, sync_a, sync_err, sync_target);
+  if (split) { if (!split_handoff(c, sync_a, sync_err, sync_target)) return; }
   else handoff_barrier();
   // first decoder layer's image: requested now, lands during the latent arithmetic
   if (MODE != 2) issue_next(c, blob_to_half(c, wsh + J->mod[split ? part : 0].dec_s[0], 0));
@@ -1509,8 +1537,6 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       GAS char* const oimg = wsh + md.out_s + (int64_t)ch * OBLOB_BYTES;
       const WgGeom Go{valid, Hl, 0, rup(Hl + 1, 16),
                       WgT{md.out_w + (int64_t)(d0 >> 4) * KTo * 256, md.out_b + d0, oimg, LDP * 2, (GAS float*)(oimg + OIMG_BYTES), opatch}};
-      const bool adam_on = bwd && (c.flags & NM_F_ADAM);
-      PMV pm_a, pm_b;
       if (c.tid < OCH) c.colacc[c.tid] = 0.f;
       // chunk ch's blob (requested a chunk ago) and everything older; from the second chunk on at least the RT
       // fp32 input loads of the previous chunk are younger than it and may stay in flight (with Adam: its last stores;
@@ -1530,9 +1556,6 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
         for (int rt = 0; rt < RT; ++rt)
           exh[rt] = *(const GAS bf16x4*)(dres_in + (int64_t)ch * XIMG_BYTES + ((c.wm * WROWS + rt * 16 + c.c16) * LDX + dl0) * 2);
       }
-#if NM_PRE_OUT == 2
-      if (adam_on && c.wave < wg_units(Go)) wg_request(c, Go, c.wave, pm_a);
-#endif
       // x_hat chunk: acc[rt] = features dl0..dl0+3 of row (wm, rt, c16)
       f32x4 acc[RT];
 #pragma unroll
@@ -1679,12 +1702,6 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       if (!bwd) return;                           // forward only: the next chunk's barrier protects the slots
       lds_barrier();                              // delta chunk and column sums complete
       relaunder(c);
-#if NM_PRE_OUT == 1
-      if (adam_on && c.wave < wg_units(Go)) wg_request(c, Go, c.wave, pm_a);
-#endif
-#if NM_PRE_OUT >= 1
-      if (adam_on && c.wave + NWAVES < wg_units(Go)) wg_request(c, Go, c.wave + NWAVES, pm_b);
-#endif
       // d logvar_out for this chunk (master + the copy that travels with the chunk's image)
       if (c.tid < valid && !sigm)
         apply_grad(c, md.logvar_out + d0 + c.tid, ll_w * c.colacc[c.tid] * c.inv_b,
@@ -1694,11 +1711,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       tr(c, 8);
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Dq[r][d] P[r][k]
-#if NM_PRE_OUT >= 1
-      wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, Go, adam_on ? &pm_a : nullptr, adam_on ? &pm_b : nullptr);
-#else
       wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, Go);
-#endif
       tr(c, 9);
       prof(c, PH_OUT_WGRAD);
     };
@@ -1754,14 +1767,10 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const GAS char* act_img = d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ACT_BYTES;
       GAS char* const dimg = wsh + md.dec_s[d];
       const WgGeom Gd{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.dec_w[d], md.dec_b[d], dimg, LDP * 2, (GAS float*)(dimg + IMG_BYTES), spatch}};
-      PMV pm_d;                                   // first unit's p / m / v: in flight during the dgrad and the reloads
-#if NM_PRE_HID
-      if ((c.flags & NM_F_ADAM) && c.wave < wg_units(Gd)) wg_request(c, Gd, c.wave, pm_d);
-#endif
       dgrad_hidden(c, acc, dimg, act_img, Nout);
       tr(c, 10);
       prof(c, PH_DEC_DGRAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gd, (NM_PRE_HID && (c.flags & NM_F_ADAM)) ? &pm_d : nullptr);
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gd);
       tr(c, 11);
       prof(c, PH_DEC_WGRAD);
       if (d > 0) {
@@ -1793,7 +1802,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 
   // ================= loss log =================
   // d z (and, split: ll_m) of every decoder is complete
-  if (split) split_handoff(c, sync_b, sync_err, sync_target);
+  if (split) { if (!split_handoff(c, sync_b, sync_err, sync_target)) return; }
   else handoff_barrier();
   if (MODE != 2 && c.tid == 0 && J->loss_log && part == 0) {
     gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
@@ -1814,11 +1823,6 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // d z of shared column z = sum over the decoders, in decoder order
   // (every copy is requested before the first is used: a loop over M would wait for each in turn)
   auto load_dz = [&](int r, int z) {
-#ifdef NM_DZ_LOOP
-    float d0 = ws_dz0[r * Zs + z];
-    for (int q = 1; q < M; ++q) d0 += ws_dz0[(int64_t)q * ROWS * Zs + r * Zs + z];
-    return d0;
-#endif
     float dq[NM_MAX_MOD];
 #pragma unroll
     for (int q = 0; q < NM_MAX_MOD; ++q) dq[q] = (q < M) ? ws_dz0[(int64_t)q * ROWS * Zs + r * Zs + z] : 0.f;
@@ -2124,13 +2128,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       zero_acc(acc);
       GAS char* const eimg = wsh + md.enc_s[e];
       const WgGeom Ge{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.enc_w[e], md.enc_b[e], eimg, LDP * 2, (GAS float*)(eimg + IMG_BYTES), spatch}};
-      PMV pm_e;
-#if NM_PRE_HID
-      if ((c.flags & NM_F_ADAM) && c.wave < wg_units(Ge)) wg_request(c, Ge, c.wave, pm_e);
-#endif
       dgrad_hidden(c, acc, eimg, ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout);
       prof(c, PH_ENCB_DGRAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Ge, (NM_PRE_HID && (c.flags & NM_F_ADAM)) ? &pm_e : nullptr);
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Ge);
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
       lds_barrier();
@@ -2145,40 +2145,18 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const GAS char* xsrc = (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * nch * XIMG_BYTES;
       GAS char* img = wsh + md.enc_s[0];
       dma_lin<0>(c, xsrc, Qb, XIMG_BYTES >> 10);
-      const bool adam_on = NM_PRE_L0 && (c.flags & NM_F_ADAM) != 0;
       auto geom = [&](int kc) {
         return WgGeom{N0, K0, kc * XCH, min(XCH, Kx - kc * XCH),
                       WgT{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * W0IMG_BYTES, LDX * 2,
                           (GAS float*)(img + (int64_t)nch * W0IMG_BYTES), spatch}};
       };
-      // p / m / v of pass kc + 1 (both units of this wave) are requested at the start of pass kc: two register sets
-      // that swap roles from pass to pass (the loop is unrolled by two so that the sets keep their names)
-      PMV ea0, ea1, eb0, eb1;
-      auto request_pass = [&](int kc, PMV& s0, PMV& s1) {
-        if (!adam_on || kc >= nch) return;
-        const WgGeom Gn = geom(kc);
-        if (c.wave < wg_units(Gn)) wg_request(c, Gn, c.wave, s0);
-        if (c.wave + NWAVES < wg_units(Gn)) wg_request(c, Gn, c.wave + NWAVES, s1);
-      };
-      request_pass(0, ea0, ea1);
-      for (int kc = 0; kc < nch; kc += 2) {
-        wait_vm(0);
+      int young = 0;                              // operations younger than the copy of chunk kc (the previous pass's)
+      for (int kc = 0; kc < nch; ++kc) {
+        wait_vm(min(young, 20));                  // its Adam stores stay in flight
         lds_barrier();                            // chunk kc has landed everywhere; chunk kc - 1 is finished everywhere
         if (kc + 1 < nch) dma_lin<0>(c, xsrc + (int64_t)(kc + 1) * XIMG_BYTES, Qb + ((kc + 1) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
-        request_pass(kc + 1, eb0, eb1);
-        {
-          const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + (kc & 1) * XIMG_BYTES);
-          wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc), adam_on ? &ea0 : nullptr, adam_on ? &ea1 : nullptr);
-        }
-        if (kc + 1 >= nch) break;
-        wait_vm(0);
-        lds_barrier();
-        if (kc + 2 < nch) dma_lin<0>(c, xsrc + (int64_t)(kc + 2) * XIMG_BYTES, Qb + ((kc + 2) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
-        request_pass(kc + 2, ea0, ea1);
-        {
-          const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + ((kc + 1) & 1) * XIMG_BYTES);
-          wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc + 1), adam_on ? &eb0 : nullptr, adam_on ? &eb1 : nullptr);
-        }
+        const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + (kc & 1) * XIMG_BYTES);
+        young = wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc));
       }
       prof(c, PH_ENCB_L0_WGRAD);
     }
@@ -2187,7 +2165,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
 }
 
 // ----------------------------------------------------------------------------------------------
-constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + STAGE_FLOATS * 4 + 2 * VEC_BYTES + (64 + 128 + 256 + 256 + 16) * 4;
+constexpr int SMEM_BYTES = 2 * ROWS * LDP * 2 + STAGE_FLOATS * 4 + 2 * VEC_BYTES + (64 + 128 + 256 + 256 + 128 + 16 + 4) * 4;
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 static_assert(XIMG_BYTES + OBLOB_BYTES + NWAVES * PATCH_FLOATS * 4 <= ACT_BYTES, "output-chunk layout of Q");
 static_assert(2 * XIMG_BYTES - ACT_BYTES <= SPATCH_OFF && SPATCH_OFF + NWAVES * PATCH_FLOATS * 4 <= STAGE_FLOATS * 4, "S layout");
@@ -2201,7 +2179,9 @@ __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
   c.colacc = c.red + 64;
   c.rowacc = c.colacc + 128;
   c.lse = c.rowacc + 256;
-  c.tlast = reinterpret_cast<unsigned long long*>(c.lse + 256);
+  c.bgrad = c.lse + 256;
+  c.tlast = reinterpret_cast<unsigned long long*>(c.bgrad + 128);
+  c.abort = reinterpret_cast<unsigned*>(c.tlast + 8);
 }
 
 template <bool SCALAR_TR, int MODE = 0>
@@ -2217,6 +2197,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     job_idx = (idx / nparts) * 8 + xcd;
     part = idx % nparts;
     if (job_idx >= n_jobs) return;
+    if ((flags & NM_F_FAULT_INJECT) && part == 1) return;    // diagnostic: a part that never arrives (time-out test)
   }
   const int tile_idx = blockIdx.y;
   const nm_job_t* J = jobs + job_idx;
@@ -2271,6 +2252,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     lds_barrier();
     relaunder(c);
     run_step<SCALAR_TR, MODE>(c, s);
+    if ((flags & NM_F_SPLIT) && *c.abort != 0u) break;       // a hand-off timed out (wave-uniform: LDS word read by all)
     tr(c, 62);
     // the next step reads what this one stored (weights, shadow images, workspace): drain, then meet
     handoff_barrier();
@@ -2991,7 +2973,19 @@ __global__ void sync_reset_kernel(const nm_job_t* __restrict__ jobs, int n_jobs)
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n_jobs * (WS_SYNC_BYTES / 4)) {
     const nm_job_t* J = jobs + j / (WS_SYNC_BYTES / 4);
-    ((unsigned*)((char*)J->workspace + ws_layout(J->M, J->L, J->Z).sync))[j % (WS_SYNC_BYTES / 4)] = 0u;
+    const int w = j % (WS_SYNC_BYTES / 4);
+    if (w != WS_SYNC_ERR_WORD)              // the error word is sticky: read by nm_split_errors, cleared by its `clear`
+      ((unsigned*)((char*)J->workspace + ws_layout(J->M, J->L, J->Z).sync))[w] = 0u;
+  }
+}
+// out[j] = error word of job j (a split launch's hand-off timed out); clear != 0 zeroes the words afterwards
+__global__ void split_errors_kernel(const nm_job_t* __restrict__ jobs, int n_jobs, int* __restrict__ out, int clear) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_jobs) {
+    const nm_job_t* J = jobs + j;
+    unsigned* w = (unsigned*)((char*)J->workspace + ws_layout(J->M, J->L, J->Z).sync) + WS_SYNC_ERR_WORD;
+    out[j] = (int)*w;
+    if (clear) *w = 0u;
   }
 }
 
@@ -3333,6 +3327,7 @@ static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int step
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(n_jobs, n_tiles), block(WG);
   flags &= ~NM_F_SPLIT;
+  if (parts <= 1) flags &= ~NM_F_FAULT_INJECT;
   if (parts > 1) {
     // several workgroups per model: they wait for each other inside the launch, so every one of them must be
     // resident at once -- one workgroup per CU (LDS), hence at most as many workgroups as the device has CUs
@@ -3370,6 +3365,15 @@ int nm_launch_split(const nm_job_t* jobs_dev, int n_jobs, int parts, int step0, 
   return launch_impl(jobs_dev, n_jobs, step0, n_steps, 1, flags, stream, false, parts);
 }
 
+/* Error words of the jobs' split launches: out_dev[j] != 0 <=> a hand-off of job j timed out in some nm_launch_split
+ * since the words were last cleared (its parts left the launch; the parameters are not to be trusted). */
+int nm_split_errors(const nm_job_t* jobs_dev, int n_jobs, int* out_dev, int clear, void* stream) {
+  if (!jobs_dev || !out_dev) return -1;
+  if (n_jobs < 1) return -8;
+  hipLaunchKernelGGL(split_errors_kernel, dim3((n_jobs + 255) / 256), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs, out_dev, clear);
+  return (int)hipGetLastError();
+}
+
 int nm_launch(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags,
               void* stream) {
   return launch_impl(jobs_dev, n_jobs, step0, steps_per_tile, n_tiles, flags, stream, false);
@@ -3384,6 +3388,8 @@ int nm_launch_scalar_tr(const nm_job_t* jobs_dev, int n_jobs, int step0, int ste
 int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags, void* stream) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1 || n_tiles < 1 || step < 0 || tile0 < 0) return -8;
+  // concurrent tiles of one job share its parameters, moments, gradient buffer and reg_dres: forward-only
+  if (n_tiles > 1 && (flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return -8;
   hipError_t e = hipFuncSetAttribute((const void*)nm_reghead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nm_reghead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,
@@ -3394,6 +3400,7 @@ int nm_head_regression(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0
 int nm_head_classifier(const nm_job_t* jobs_dev, int n_jobs, int step, int tile0, int n_tiles, int flags, void* stream) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1 || n_tiles < 1 || step < 0 || tile0 < 0) return -8;
+  if (n_tiles > 1 && (flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return -8;
   hipError_t e = hipFuncSetAttribute((const void*)nm_clshead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nm_clshead_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step,

@@ -50,6 +50,7 @@ class Table:
         # checksums of the bytes; device tensors: identity of the storage (no device-to-host copy, no sync)
         if torch.is_tensor(c) and c.is_cuda:
             self.c_key = ("dev", c.data_ptr(), tuple(c.shape), str(c.dtype), c._version)
+            self._keep = (c,)            # the key is the storage's identity: the storage must outlive the table
         else:
             c_host = c.detach().contiguous().numpy() if torch.is_tensor(c) else np.ascontiguousarray(np.asarray(c))
             self.c_key = (tuple(c_host.shape), str(c_host.dtype), zlib.crc32(c_host.tobytes()), zlib.adler32(c_host.tobytes()))
@@ -391,6 +392,24 @@ class JobSet:
         self.lib = _lib.load()
         self._dev = None
         self._sig = None
+        self._split_pending = False      # a split launch has run since the hand-off error words were last read
+
+    def check_split_errors(self):
+        """Raise NmError if a hand-off of a split launch (one workgroup per modality) timed out since the last check:
+        the job's workgroups left that launch, its parameters are not to be trusted.  Called before the next launch
+        of this set and by everything that reads results (assert_finite, losses, sweep.save_model); costs one small
+        kernel + a 4-byte-per-job copy, and only after a split launch."""
+        if not self._split_pending or self._dev is None:
+            return
+        out = torch.zeros(len(self.jobs), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.nm_split_errors(self._dev.data_ptr(), len(self.jobs), out.data_ptr(), 1,
+                                            _stream_ptr(self.device)), "nm_split_errors")
+        self._split_pending = False
+        bad = out.nonzero().flatten().tolist()
+        if bad:
+            raise _lib.NmError(f"split launch: the hand-off between the workgroups of job(s) {bad[:8]} timed out "
+                               f"(the parts of a model must all be resident at once: another stream or process "
+                               f"occupying CUs breaks that); their parameters are not valid -- re-run with NMHIP_SPLIT=0")
 
     def _set_dephase(self):
         """Start offsets of the jobs of a long launch (nm_job_t.dephase): workgroup b lands on XCD b mod 8 (observed
@@ -422,6 +441,7 @@ class JobSet:
     def _upload(self, n_tiles: int = 1):
         """Descriptor array on the device; rebuilt only when a job's descriptor changed (the
         optimizer step count rides on adam_off = t - step, constant while both advance)."""
+        self.check_split_errors()
         self._set_dephase()
         for j in self.jobs:
             j._ensure_workspace(n_tiles)
@@ -469,6 +489,7 @@ class JobSet:
             ptr = self._upload(1)
             _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), parts, int(step0), int(n_steps), int(flags),
                                                 _stream_ptr(self.device)), "nm_launch_split")
+            self._split_pending = True
         else:
             self._launch(step0, n_steps, 1, flags, scalar_tr)
         for j in self.jobs:
@@ -483,6 +504,7 @@ class JobSet:
             ptr = self._upload(1)
             _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), len(self.jobs[0].kmods), int(s), 1, int(flags),
                                                 _stream_ptr(self.device)), "nm_launch_split")
+            self._split_pending = True
         else:
             self._launch(s, 1, 1, flags, scalar_tr)
 
@@ -575,6 +597,7 @@ class JobSet:
 
     def losses(self) -> torch.Tensor:
         """[n_jobs, loss_cap, 8] on the host."""
+        self.check_split_errors()
         return torch.stack([j.loss_log for j in self.jobs]).cpu()
 
     def synchronize(self):
@@ -583,7 +606,9 @@ class JobSet:
     def assert_finite(self):
         """Failure detection, once per epoch / run rather than per step (the reference prints NaNs from inside
         its hot loop, cVAE.py:1169-1172): one device reduction over every job's loss ring; raises NmError naming
-        the first job whose log holds a non-finite value."""
+        the first job whose log holds a non-finite value.  Also the point where a timed-out hand-off of a split
+        launch surfaces at the latest (check_split_errors)."""
+        self.check_split_errors()
         logs = torch.stack([j.loss_log for j in self.jobs])
         ok = torch.isfinite(logs).flatten(1).all(dim=1)
         if not bool(ok.all()):

@@ -136,8 +136,12 @@ def run_cells(cohort: prep.SyntheticCohort, cells: Sequence[Cell], n_folds: int,
     if models_dir is not None:
         # what the train script leaves for the test script (cVAE_model.pkl per fold, ...train...py:211-212), as the
         # state_dict under the reference's key names + the constructor arguments
+        # ... plus the fold's own train / test subjects (the reference's train_ids_{fold}.csv / test_ids_{fold}.csv,
+        # utils.py:88-93): the `test` subcommand scores exactly the rows this model did not train on, whichever
+        # fold recipe (-O / -TrainingClass) produced them
         for c, j in zip(cells, jobs):
-            save_model(Path(models_dir) / c.procedure / f"{c.fold:03d}", j, model)
+            save_model(Path(models_dir) / c.procedure / f"{c.fold:03d}", j, model,
+                       train_ids=cohort.iid[folds[c.fold][0]], test_ids=cohort.iid[folds[c.fold][1]])
     sps = total_steps / max(time.perf_counter() - t0, 1e-9)
     # deviation pass: ONE forward-only launch for every (cell, modality) of this rank (unimodal views of the trained
     # models on the all-subject tables, one workgroup per (view, 256-row tile)); the per-subject score (mean over
@@ -373,11 +377,16 @@ def run_endtoend_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int]
     return out
 
 
-def save_model(fold_dir, job: Job, model: str = "cVAE_multimodal") -> Path:
+def save_model(fold_dir, job: Job, model: str = "cVAE_multimodal", train_ids=None, test_ids=None) -> Path:
     """<fold_dir>/cVAE_model_state.pt: {'state_dict': reference-keyed tensors, 'input_dim_list', 'hidden_dim', 'latent_dim',
-    'c_dim', 'model', 'combine'} -- loadable by the reference class (`load_state_dict`) and by load_model."""
+    'c_dim', 'model', 'combine'} -- loadable by the reference class (`load_state_dict`) and by load_model.  With the
+    fold's subjects given, also train_ids.csv / test_ids.csv (one IID column, the files of utils.py:88-93)."""
     fold_dir = Path(fold_dir)
     fold_dir.mkdir(parents=True, exist_ok=True)
+    if train_ids is not None and test_ids is not None:
+        import pandas as pd
+        pd.DataFrame({"IID": np.asarray(train_ids)}).to_csv(fold_dir / "train_ids.csv", index=False)
+        pd.DataFrame({"IID": np.asarray(test_ids)}).to_csv(fold_dir / "test_ids.csv", index=False)
     sp = job.spec
     path = fold_dir / "cVAE_model_state.pt"
     torch.save({"state_dict": {k: v.cpu() for k, v in job.state_dict().items()}, "input_dim_list": list(sp.input_dims),
@@ -409,9 +418,12 @@ def test_fold(job: Job, cohort: prep.SyntheticCohort, train_rows: np.ndarray, te
         src = prep.source_table(cohort, m)
         center, scale = prep.robust_scaler_fit(src[train_rows])
         xs.append(prep.robust_scaler_transform(src[test_rows], center, scale).astype(np.float32))
-    cov = prep.one_hot_covariates(cohort.age[test_rows], cohort.gender[test_rows])
+    # (the DMVAE family's networks take no covariates: net_c_dim = 0 and a table without the covariate block)
+    cov = (prep.one_hot_covariates(cohort.age[test_rows], cohort.gender[test_rows]) if job.spec.net_c_dim > 0
+           else np.zeros((len(test_rows), 0), dtype=np.float32))
     tables = [Table(x, cov, device) for x in xs]
-    ev = Job(job.spec, tables, combine=combine, state=job.state_dict(), seed=job.seed + 31, n_tiles_ws=tables[0].n_tiles)
+    ev = Job(job.spec, tables, combine=combine, state=job.state_dict(), seed=job.seed + 31, n_tiles_ws=tables[0].n_tiles,
+             single_bypass=job.single_bypass)
     ev.enable_exports(loc=True, sqerr=False, rowdev=True, latent=False)
     JobSet([ev]).forward()
     torch.cuda.synchronize(device)
@@ -686,8 +698,16 @@ def main_test(argv=None):
         # (the model is rebuilt on any tables of the right widths; test_fold puts it on the fold's test tables)
         meta = torch.load(fold_dir / "cVAE_model_state.pt", map_location="cpu", weights_only=True)
         no_cov = MODEL_KINDS[meta["model"]][0] in ("dmvae", "weighted_dmvae", "mmvaeplus")
+        # the fold's subjects as the train entry recorded them (its -O / -TrainingClass recipe may differ from the
+        # plain KFold); models saved without them: the plain KFold split
+        if (fold_dir / "train_ids.csv").exists() and (fold_dir / "test_ids.csv").exists():
+            tr = prep.rows_of_ids(cohort.iid, pd.read_csv(fold_dir / "train_ids.csv")["IID"].to_numpy())
+            te = prep.rows_of_ids(cohort.iid, pd.read_csv(fold_dir / "test_ids.csv")["IID"].to_numpy())
         job = load_model(fold_dir, dc.fold_tables_cached(k, mods, tr, with_covariates=not no_cov), device, seed=1000 * k)
-        err = test_fold(job, cohort, tr, te, mods, combine, device, out_dir=fold_dir)
+        # models whose class fixes the fusion (mmJSD, the DMVAE family: MODEL_KINDS[...][2]) reconstruct with the saved
+        # one, whatever the procedure name says (mmJSD.pred_recon ignores its combine argument, cVAE.py:1405-1420)
+        fold_combine = str(meta["combine"]).lower() if MODEL_KINDS[meta["model"]][2] else combine
+        err = test_fold(job, cohort, tr, te, mods, fold_combine, device, out_dir=fold_dir)
         for m in mods:
             errors[m].append(err[m])
     for m in mods:                                   # all folds of this rank, one table per CSV kind (:147-175)
