@@ -42,6 +42,53 @@ def kernel_src_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def device_record(torch, nm, js, dev):
+    """Clocks of this run: what the runtime reports, what sysfs shows (where readable), and the shader clock the step
+    kernel itself saw -- cycles of one wave (clock64) over the same interval on the constant 100 MHz counter
+    (s_memrealtime), from a short NM_F_TRACE launch after the timed regions (MI355X_MICROARCH.md, DVFS give-back)."""
+    import ctypes as C
+    from multi_modal_normative_modeling_amd import _lib
+    prop = torch.cuda.get_device_properties(dev)
+    rec = {"name": prop.name, "cus": prop.multi_processor_count,
+           "clock_rate_khz": getattr(prop, "clock_rate", None), "memory_clock_rate_khz": getattr(prop, "memory_clock_rate", None)}
+    try:
+        lib = _lib.load()
+        buf, wg = (C.c_ulonglong * 512)(), (C.c_ulonglong * 1024)()
+        lib.nm_trace_read(buf, 1)
+        n = 16
+        js._launch(js.jobs[0].step, n, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | _lib.NM_F_TRACE)
+        for j in js.jobs:
+            j.step += n
+            j.t += n
+        torch.cuda.synchronize(dev)
+        lib.nm_trace_read(buf, 1)
+        lib.nm_wgtimes_read(wg)
+        cycles = sum(buf[t] for t in range(64))                     # wave 0 of workgroup (0, 0), all intervals
+        ticks = wg[1] - wg[0]                                       # the same workgroup, 100 MHz
+        if ticks > 0:
+            rec["in_kernel_shader_clock_ghz"] = round(cycles / (ticks / 1e8) / 1e9, 4)
+            rec["in_kernel_cycles_per_step"] = int(cycles / n)
+    except Exception as e:                                          # diagnostics must never fail the bench
+        rec["in_kernel_clock_error"] = repr(e)
+    sysfs = {}
+    for card in sorted(Path("/sys/class/drm").glob("card[0-9]*/device")):
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "power_dpm_force_performance_level"):
+            f = card / name
+            try:
+                sysfs[f"{card.parent.name}/{name}"] = f.read_text().strip().replace("\n", " | ")[:200]
+            except OSError:
+                pass
+        for f in card.glob("hwmon/hwmon*/power1_cap"):
+            try:
+                sysfs[f"{card.parent.name}/power1_cap_uW"] = f.read_text().strip()
+            except OSError:
+                pass
+        if len(sysfs) >= 8:
+            break
+    rec["sysfs"] = sysfs or None
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +101,9 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=128,
                     help="train steps inside one persistent launch (the timed K steps run as ceil(K / this) launches)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
+    ap.add_argument("--small-sweep", type=int, default=1,
+                    help="1: also time the metric's literal shape -- 5 folds -- and the reference's 20-cell sweep and one model "
+                         "alone (own short legs after the timed region, rank 0 at N = 1; 0 = skip)")
     ap.add_argument("--subjects", type=int, default=1280)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(affinity, 16))")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the\n                    multi-rank path on a one-GPU box together with --share-device)")
@@ -193,6 +243,35 @@ def main():
                    "train_rows_per_model": jobs[0].tables[0].N, "parallelism": f"sweep-sharded x{world}"},
         "roofline": roofline,
     }
+
+    # ---- what the record needs to explain box-to-box differences: the clocks this run saw ----
+    if rank == 0:
+        out["device"] = device_record(torch, nm, js, dev)
+
+    # ---- small sweeps: the metric's literal shape (5 folds) and the reference's real grid (20 cells), one model alone ----
+    # (own short legs OUTSIDE the timed region above; the models run as one workgroup per modality: nm_launch_split)
+    if world == 1 and args.small_sweep and args.procedure == "SE-gPoE":
+        small = {}
+        pool = workload.build_sweep_jobs(cohort, args.procedure, 5, 26, dev, seed0=10_000)
+        for name, n, lo in (("jobs5", 5, 0), ("jobs20", 20, 5), ("single_model", 1, 25)):
+            sj = nm.JobSet(pool[lo:lo + n])
+            sj.train(32)
+            torch.cuda.synchronize(dev)
+            best = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                sj.train(128)
+                torch.cuda.synchronize(dev)
+                best = min(best, time.perf_counter() - t0)
+            sj.assert_finite()
+            if name == "single_model":
+                small["single_model_us_per_step"] = round(best / 128 * 1e6, 2)
+            else:
+                small[name] = {"steps_per_s": round(n * 128 / best, 1), "us_per_sweep_step": round(best / 128 * 1e6, 2),
+                               "workgroups": n * sj.split_parts()}
+        small["note"] = "5 folds x 1 model = the metric's literal shape; 20 = 5 folds x 4 procedures; 128-step launches, best of 3"
+        out["small_sweep"] = small
+        log(f"small sweeps: {small}")
 
     # ---- the sweep's one collective, on the real payload: per-model metric rows, all_gather over the ranks ----
     nan = float("nan")

@@ -11,12 +11,14 @@ from pathlib import Path
 
 NM_MAX_MOD = 8
 NM_MAX_EXP = 4
-NM_MAX_HID = 3
+NM_MAX_HID = 8
 NM_MAX_CLS = 3
 NM_MAX_CLASSES = 4
 NM_BATCH = 256
 NM_MAX_WIDTH = 127
 NM_MAX_LATENT = 64
+NM_WIDE_MAX_WIDTH = 4096
+NM_WIDE_MAX_LATENT = 128
 NM_LOSS_STRIDE = 16
 
 NM_COMBINE = {"poe": 0, "gpoe": 1, "moe": 2, "mopoe": 3, "poe2v": 4}
@@ -64,7 +66,7 @@ class NmJob(C.Structure):
         ("H", C.c_int32 * NM_MAX_HID),
         ("combine", C.c_int32), ("single_bypass", C.c_int32), ("n_rows", C.c_int32), ("non_linear", C.c_int32),
         ("act_slope", C.c_float), ("out_kind", C.c_int32), ("n_private", C.c_int32),
-        ("var_floor", C.c_float), ("tc_weight", C.c_float), ("w_off", C.c_int64), ("dephase", C.c_int32), ("shared_cov", C.c_int32),
+        ("var_floor", C.c_float), ("tc_weight", C.c_float), ("w_off", C.c_int64), ("dephase", C.c_int32), ("shared_cov", C.c_int32), ("wide", C.c_int32),
         ("loss_cap", C.c_int32), ("eps_cap", C.c_int32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("adam_off", C.c_int64), ("lr_table", C.c_void_p), ("lr_cap", C.c_int32),
@@ -121,7 +123,10 @@ def load():
     for name in ("nm_launch", "nm_launch_scalar_tr"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_launch_split.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.nm_launch_wide.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_split_errors.argtypes = [vp, i32, vp, i32, vp]
+    lib.nm_combine_latent.argtypes = [vp, vp, i32, i64, i32, vp, i32, i32, i32, f32, vp, vp, vp]
+    lib.nm_total_correlation.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_train_steps_persistent.argtypes = [vp, i32, i32, i32, vp]
     lib.nm_deviation.argtypes = [vp, i32, i32, i32, vp]
@@ -155,7 +160,7 @@ EXPORTED_SYMBOLS = [
     "nm_version", "nm_status_string", "nm_abi_sizes", "nm_workspace_bytes", "nm_validate_job", "nm_launch",
     "nm_launch_scalar_tr", "nm_train_steps", "nm_grads", "nm_forward", "nm_adam_step", "nm_pack_table",
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_wgtimes_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
-    "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split", "nm_split_errors",
+    "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split", "nm_launch_wide", "nm_split_errors", "nm_combine_latent", "nm_total_correlation",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
 ]
 

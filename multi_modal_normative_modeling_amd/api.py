@@ -277,7 +277,53 @@ def _lib_loss(which):
     return {"TOTAL": 0, "KL": 1, "LL": 2}[which]
 
 
-class cVAE_multimodal(_Base):
+class _ExpertOps:
+    """The reference's public expert-fusion methods (cVAE.py:1118-1126, 1144-1164; :2265-2307 on the regression class)
+    as forward-only launches of nm_combine_latent: tensors [M, B, Z] in, (mu, variance) [B, Z] on the device out."""
+    _fuse_bypass = True          # combine_latent returns a single expert as it is (cVAE.py:1146-1147)
+    _fuse_floor = 0.0
+    _bad_combine = "No such combination method"
+
+    def _fuse(self, mus, variances, combine: str, in_log: bool = False, out_log: bool = False, bypass: bool = False,
+              floor: float = 0.0):
+        dev = self._dev()
+        mu = torch.as_tensor(mus, dtype=torch.float32).to(dev).contiguous()
+        var = torch.as_tensor(variances, dtype=torch.float32).to(dev).contiguous()
+        if mu.shape != var.shape or mu.dim() < 2:
+            raise ValueError(f"mus / variances must be [M, ...] tensors of equal shape, got {tuple(mu.shape)} / {tuple(var.shape)}")
+        M, n = int(mu.shape[0]), int(mu[0].numel())
+        alpha = None
+        if combine == "gpoe":                       # softmax(alpha_m_list) inside the kernel (cVAE.py:1155)
+            alpha = torch.cat([self._views()[f"alpha_m_list.{m}"].reshape(1) for m in range(self.modalities)]).to(dev).contiguous()
+            if M != self.modalities:
+                raise ValueError(f"gpoe needs one expert per modality ({self.modalities}), got {M}")
+        out_mu, out_var = torch.empty_like(mu[0]), torch.empty_like(mu[0])
+        lib = _lib.load()
+        _lib.check(lib.nm_combine_latent(mu.data_ptr(), var.data_ptr(), M, n, _lib.NM_COMBINE[combine],
+                                         alpha.data_ptr() if alpha is not None else None, int(bypass), int(in_log), int(out_log),
+                                         float(floor), out_mu.data_ptr(), out_var.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream), "nm_combine_latent")
+        return out_mu, out_var
+
+    def product_of_experts(self, mus, variances):
+        return self._fuse(mus, variances, "poe")
+
+    def mixture_of_experts(self, mus, variances):
+        return self._fuse(mus, variances, "moe")
+
+    def mixture_of_product_of_experts(self, mus, variances):
+        return self._fuse(mus, variances, "mopoe")
+
+    def combine_latent(self, mus, variances, combine):
+        combine = combine.lower()
+        if self._fuse_bypass and int(mus.shape[0]) == 1:
+            combine = "poe"                          # (the bypass returns before the reference looks at `combine`)
+        if combine not in ("poe", "gpoe", "moe", "mopoe"):
+            raise ValueError(self._bad_combine.format(combine=combine))
+        return self._fuse(mus, variances, combine, bypass=self._fuse_bypass, floor=self._fuse_floor)
+
+
+class cVAE_multimodal(_ExpertOps, _Base):
     """cVAE.py:1087-1211."""
 
     def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3,
@@ -435,11 +481,39 @@ class mvtCAE(cVAE_multimodal):
         self._ll_weight = -1e-5
         self.optimizer1 = _Adam(self, learning_rate)
 
+    _fuse_bypass = False         # cVAE.py:1800-1825: no single-expert bypass, joint variance clamped at 1e-6
+    _fuse_floor = 1e-6
+
     @staticmethod
     def _kernel_combine(combine):
         if combine.lower() not in ("poe", "gpoe", "moe", "mopoe"):
             raise ValueError("No such combination method")
         return "poe2v" if combine.lower() == "poe" else combine
+
+    def product_of_experts(self, mus, variances):
+        """ProductOfExperts2 applied to what it is given (cVAE.py:1782-1783, 1481-1489): the second argument is read as
+        LOG variances and a log variance comes back -- the reference's own call passes variances; kept as written."""
+        return self._fuse(mus, variances, "poe", in_log=True, out_log=True)
+
+    def combine_latent(self, mus, variances, combine):
+        combine = combine.lower()
+        if combine not in ("poe", "gpoe", "moe", "mopoe"):
+            raise ValueError("No such combination method")
+        if combine == "poe":
+            return self._fuse(mus, variances, "poe", in_log=True, out_log=True, floor=self._fuse_floor)
+        return self._fuse(mus, variances, combine, floor=self._fuse_floor)
+
+    def total_correlation(self, qz_xs, qz_x):
+        """cVAE.py:1859-1866 on the device (nm_total_correlation).  qz_xs: [M, B, Z] tensor or list of [B, Z]; `qz_x`
+        enters the reference's expression only as a scalar minus its own mean, i.e. not at all."""
+        dev = self._dev()
+        q = (torch.stack([torch.as_tensor(t, dtype=torch.float32) for t in qz_xs]) if isinstance(qz_xs, (list, tuple))
+             else torch.as_tensor(qz_xs, dtype=torch.float32)).to(dev).contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().nm_total_correlation(q.data_ptr(), int(q.shape[0]), int(q.shape[1]), int(q.shape[2]),
+                                                    out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                   "nm_total_correlation")
+        return out[0]
 
     def forward_multimodal(self, xes, cs, combine):
         out = super().forward_multimodal(xes, cs, self._kernel_combine(combine))
@@ -463,9 +537,13 @@ class mmJSD(cVAE_multimodal):
     with itself (`multimodal_jsd([mu_multimodal] * M, ...)`, :1426), i.e. it is identically zero with zero
     gradient.  So the step kernel runs it unchanged: PoE, bypass off; `alpha_m_list` receives no gradient."""
 
-    def __init__(self, *a, **k):
-        super().__init__(*a, **k)
+    def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3, non_linear=False):
+        super().__init__(input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate, modalities, non_linear)
         self._single_bypass = False
+
+    def combine_latent(self, mus, logvars):
+        """cVAE.py:1399-1402: plain product of experts on LOG variances, the joint variance comes back; no bypass."""
+        return self._fuse(mus, logvars, "poe", in_log=True)
 
     def forward_multimodal(self, xes, cs, combine):
         return super().forward_multimodal(xes, cs, "poe")
@@ -556,7 +634,7 @@ class _RegTotal(torch.autograd.Function):
         return None, None, None
 
 
-class cVAE_multimodal_regression(_HeadBase):
+class cVAE_multimodal_regression(_ExpertOps, _HeadBase):
     """cVAE.py:2211-2346: cVAE_multimodal + a regressor on the concatenated residuals.  Trunk and regressor
     both run in HIP (nm_launch + nm_head_regression); the regressor's tensors live in the same flat
     parameter buffer under the reference's names regressor.{0,2,4}.{weight,bias}."""
@@ -571,6 +649,8 @@ class cVAE_multimodal_regression(_HeadBase):
                     learning_rate, kl_weight=float(modalities))
         self.mse_loss = nn.MSELoss()
         self.optimizer1 = _Adam(self, learning_rate)
+
+    _bad_combine = "Invalid combine strategy: {combine}"         # cVAE.py:2307
 
     def forward_multimodal(self, xes, cs, combine):
         if combine.lower() not in _lib.NM_COMBINE:
@@ -785,9 +865,8 @@ class cVAE_multimodal_endtoend(_HeadBase):
         return torch.stack(mus), torch.stack(lvs)
 
     def combine_latent(self, mus, logvars):
-        """cVAE.py:2083-2090 (product of experts, no single-expert bypass)."""
-        T = 1 / torch.exp(logvars)
-        return torch.sum(mus * T, dim=0) / torch.sum(T, dim=0), torch.log(1 / torch.sum(T, dim=0))
+        """cVAE.py:2083-2090 (product of experts on log variances, a log variance back; no single-expert bypass)."""
+        return _ExpertOps._fuse(self, mus, logvars, "poe", in_log=True, out_log=True)
 
     def decode(self, z, cs, group):
         """cVAE.py:2092-2104: every modality's reconstruction from one decoder bank."""

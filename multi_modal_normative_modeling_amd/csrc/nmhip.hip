@@ -809,7 +809,8 @@ __device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], co
 }
 // Hidden-layer backward, first half: P = delta of the layer's output [256][N].  The layer's weight image goes to
 // the lower half of Q and, meanwhile, rows 128..255 of the layer's saved INPUT activation to the upper half; after
-// the dgrad the lower 128 rows follow, so that on return Q = input activation (for wgrad and the ReLU mask).
+// the dgrad the lower 128 rows follow (still in flight on return: the caller's wgrad_adam(..., pending = 0) waits), so that
+// Q = input activation for wgrad and the ReLU mask.
 __device__ __forceinline__ void dgrad_hidden(const Ctx& cc, f32x4 (&acc)[2][RT], const GAS char* w_img, const GAS char* act_img,
                                              int N) {
   Ctx c = cc;
@@ -821,9 +822,7 @@ __device__ __forceinline__ void dgrad_hidden(const Ctx& cc, f32x4 (&acc)[2][RT],
   lds_barrier();
   dgrad_tile(c, acc, c.P, LDP, 0, c.Q, LDP, wpad(N) / 32);
   lds_barrier();                              // weight image fully read
-  dma_lin(c, act_img, Qb, IMG_BYTES >> 10);
-  wait_vm(0);
-  lds_barrier();
+  dma_lin(c, act_img, Qb, IMG_BYTES >> 10);   // waited for by the weight-gradient pass that follows (wgrad_adam, pending = 0)
 }
 
 // P[r][k] = acc[k][r] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
@@ -906,9 +905,12 @@ constexpr int WG_LOADS = 6;      // vector-memory operations of one wg_issue
 
 // Returns a LOWER bound of the vector-memory operations this wave issued here (for the caller's counted waits on
 // copies it requested before the call).
+// `pending` >= 0: the caller has LDS-DMA copies of the operands in flight (and `pending` vector-memory operations issued
+// after them); they are waited for here, AFTER this pass's first requests are on their way (one memory round trip saved
+// per call), followed by the workgroup barrier that makes them visible.
 template <bool SCALAR_TR>
 __device__ __forceinline__ int wgrad_adam(const Ctx& cc, const __bf16* A, int lda, int a_col0, const __bf16* B, int ldb,
-                                          const WgGeom& G) {
+                                          const WgGeom& G, int pending = -1) {
   Ctx c = cc;
   relaunder(c);
   const nm_job_t* J = c.job;
@@ -1047,6 +1049,10 @@ __device__ __forceinline__ int wgrad_adam(const Ctx& cc, const __bf16* A, int ld
   asm volatile("" : "=v"(sb.p0), "=v"(sb.m0), "=v"(sb.v0), "=v"(sb.p1), "=v"(sb.m1), "=v"(sb.v1));
   int u = c.wave, st_prev = 0;
   if (do_adam && u < nunits) { issue(u, sa); young += WG_LOADS; }
+  if (pending >= 0) {
+    wait_vm(min(pending + young + (bias_wave ? 3 : 0), 20));
+    lds_barrier();
+  }
   while (u < nunits) {
     f32x4 acc[2];
     const int u1 = u + NWAVES, u2 = u + 2 * NWAVES;
@@ -1538,11 +1544,22 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const WgGeom Go{valid, Hl, 0, rup(Hl + 1, 16),
                       WgT{md.out_w + (int64_t)(d0 >> 4) * KTo * 256, md.out_b + d0, oimg, LDP * 2, (GAS float*)(oimg + OIMG_BYTES), opatch}};
       if (c.tid < OCH) c.colacc[c.tid] = 0.f;
+      // d logvar_out of this chunk is applied after the epilogue by one lane per column (wave 0): its p / m / v are
+      // requested now (hand-issued: a plain load there would wait for every older store of this wave), and are complete
+      // by then -- the epilogue consumes this chunk's fp32 inputs, which are requested after them (in-order return)
+      const bool lvo_adam = bwd && (c.flags & NM_F_ADAM) && !sigm && c.wave == 0;
+      float lvp, lvm, lvv;
+      asm volatile("" : "=v"(lvp), "=v"(lvm), "=v"(lvv));
+      if (lvo_adam) {
+        const unsigned lo = (unsigned)(md.logvar_out + d0 + min(c.tid, valid - 1)) << 2;
+        gf32 Pq = asg(J->params), Mq = asg(J->adam_m), Vq = asg(J->adam_v);
+        NM_GLOAD4(lvp, lo, Pq); NM_GLOAD4(lvm, lo, Mq); NM_GLOAD4(lvv, lo, Vq);
+      }
       // chunk ch's blob (requested a chunk ago) and everything older; from the second chunk on at least the RT
       // fp32 input loads of the previous chunk are younger than it and may stay in flight (with Adam: its last stores;
       // forward only: also the previous chunk's export stores -- waiting for THEIR acknowledgements was most of a
       // forward-only chunk)
-      wait_vm(ch > 0 ? young_prev : 0);
+      wait_vm(ch > 0 ? min(young_prev + (lvo_adam ? 3 : 0), 20) : 0);
       lds_barrier();                              // ... for every wave; also: the previous chunk is finished everywhere
       int n_blob = 0;
       if (ch + 1 < nck) n_blob = dma_lin(c, oblob + (int64_t)(ch + 1) * OBLOB_BYTES, other, OBLOB_BYTES >> 10);
@@ -1703,15 +1720,27 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       lds_barrier();                              // delta chunk and column sums complete
       relaunder(c);
       // d logvar_out for this chunk (master + the copy that travels with the chunk's image)
-      if (c.tid < valid && !sigm)
+      if (lvo_adam) {                               // wave-uniform (wave 0)
+        asm volatile("" : "+v"(lvp), "+v"(lvm), "+v"(lvv));
+        if (c.tid < valid) {
+          const float g = ll_w * c.colacc[c.tid] * c.inv_b;
+          const int64_t idx = md.logvar_out + d0 + c.tid;
+          if (c.flags & NM_F_GRADS) asg(J->grads)[idx] = g;
+          adam1(adam_consts(c), g, lvp, lvm, lvv);
+          asg(J->params)[idx] = lvp; asg(J->adam_m)[idx] = lvm; asg(J->adam_v)[idx] = lvv;
+          ((GAS float*)(oblob + (int64_t)ch * OBLOB_BYTES + OIMG_BYTES))[OCH + c.tid] = lvp;
+        }
+      } else if (c.tid < valid && !sigm) {
         apply_grad(c, md.logvar_out + d0 + c.tid, ll_w * c.colacc[c.tid] * c.inv_b,
                    (GAS float*)(oblob + (int64_t)ch * OBLOB_BYTES + OIMG_BYTES) + OCH + c.tid);
+      }
       // dgrad into the last hidden activation: accg[k][r] += sum_d Dq[r][d] Wo[d0 + d][k], weights from the slot
       dgrad_tile(c, accg, Dq, LDX, 0, Wc, LDP, OCH / 32);
       tr(c, 8);
       prof(c, PH_OUT_DGRAD);
       // wgrad + Adam of this chunk of decoder_mean_layer: dWo[d][k] = sum_r Dq[r][d] P[r][k]
-      wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, Go);
+      const int n_wg = wgrad_adam<SCALAR_TR>(c, Dq, LDX, 0, c.P, LDP, Go);
+      young_prev = RT + n_wg;                     // all younger than the next chunk's blob request
       tr(c, 9);
       prof(c, PH_OUT_WGRAD);
     };
@@ -1770,7 +1799,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       dgrad_hidden(c, acc, dimg, act_img, Nout);
       tr(c, 10);
       prof(c, PH_DEC_DGRAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gd);
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gd, 0);
       tr(c, 11);
       prof(c, PH_DEC_WGRAD);
       if (d > 0) {
@@ -2107,17 +2136,16 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     dgrad_tile(c, acc, c.P, LDP, 0, c.Q, LDP, (2 * Zs) / 32);
     lds_barrier();                                  // image fully read
     prof(c, PH_ENCB_HEADS_DGRAD);
-    dma_lin(c, act_last, Qb, IMG_BYTES >> 10);
-    wait_vm(0);
-    lds_barrier();
+    dma_lin(c, act_last, Qb, IMG_BYTES >> 10);   // (waited for inside the first weight-gradient pass)
     tr(c, 13);
     {
       GAS char* img = wsh + md.heads_s;
       const WgGeom Gm{Z, Hh, 0, rup(Hh + 1, 16), WgT{md.mu_w, md.mu_b, img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch}};
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gm);
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gm, 0);
       const WgGeom Gl{Z, Hh, 0, rup(Hh + 1, 16),
                       WgT{md.lv_w, md.lv_b, img + (int64_t)Zs * LDP * 2, LDP * 2, (GAS float*)(img + IMG_BYTES) + Zs, spatch}};
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Gl);
+      // (pending = 0: its barrier also separates this pass's bias hand-off through LDS from the previous pass's)
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Gl, 0);
     }
     prof(c, PH_ENCB_HEADS_WGRAD);
     finish_delta(c, acc, c.Q, Hh, nl);              // P = delta of h_{L-1}
@@ -2130,7 +2158,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       const WgGeom Ge{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.enc_w[e], md.enc_b[e], eimg, LDP * 2, (GAS float*)(eimg + IMG_BYTES), spatch}};
       dgrad_hidden(c, acc, eimg, ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout);
       prof(c, PH_ENCB_DGRAD);
-      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Ge);
+      wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Ge, 0);
       prof(c, PH_ENCB_WGRAD);
       finish_delta(c, acc, c.Q, Kin, nl);
       lds_barrier();
@@ -2150,13 +2178,14 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
                       WgT{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * W0IMG_BYTES, LDX * 2,
                           (GAS float*)(img + (int64_t)nch * W0IMG_BYTES), spatch}};
       };
-      int young = 0;                              // operations younger than the copy of chunk kc (the previous pass's)
+      // chunk kc + 1 is requested as soon as every wave is done with chunk kc - 1 (the barrier that ends pass kc - 1) and
+      // lands during pass kc; pass kc waits for chunk kc itself, after its own first requests (pending = what this
+      // wave issued after that copy: the next chunk's pieces)
       for (int kc = 0; kc < nch; ++kc) {
-        wait_vm(min(young, 20));                  // its Adam stores stay in flight
-        lds_barrier();                            // chunk kc has landed everywhere; chunk kc - 1 is finished everywhere
-        if (kc + 1 < nch) dma_lin<0>(c, xsrc + (int64_t)(kc + 1) * XIMG_BYTES, Qb + ((kc + 1) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
+        int n_next = 0;
+        if (kc + 1 < nch) n_next = dma_lin<0>(c, xsrc + (int64_t)(kc + 1) * XIMG_BYTES, Qb + ((kc + 1) & 1) * XIMG_BYTES, XIMG_BYTES >> 10);
         const __bf16* Xc = reinterpret_cast<const __bf16*>(Qb + (kc & 1) * XIMG_BYTES);
-        young = wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc));
+        wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, Xc, LDX, geom(kc), n_next);
       }
       prof(c, PH_ENCB_L0_WGRAD);
     }
@@ -2260,6 +2289,8 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
   }
   if ((flags & 64) && blockIdx.y == 0 && blockIdx.x < 512 && threadIdx.x == 0) nm_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 }
+
+#include "nm_wide.inc"
 
 // ---- regression head (cVAE.py:2249-2253 regressor, 2318-2321 forward, 2330-2346 loss) ----------------
 // fi_pred = W3 relu(W2 relu(W1 cat_m(x_m - x_hat_m) + b1) + b2) + b3;  loss = mean_r (fi_pred - FI)^2.
@@ -3170,7 +3201,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 6; }
+int nm_version(void) { return 7; }
 
 /* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {
@@ -3220,6 +3251,7 @@ const char* nm_status_string(int status) {
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
     case -18: return "out_kind must be 0 or 1, 0 <= n_private <= Z, and a private latent needs an encoder per decoder";
+    case -19: return "general-shape path (wide): plain cVAE / cVAE_multimodal models only (no heads, no DMVAE-family or mvtCAE switches)";
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
@@ -3238,15 +3270,25 @@ int nm_validate_job(const nm_job_t* j) {
   if (j->M < 1 || j->M > NM_MAX_MOD) return -2;
   if (j->M_enc < 0 || j->M_enc > j->M || (j->M_enc == 0 ? j->M : j->M_enc) > NM_MAX_EXP) return -2;
   if (j->L < 1 || j->L > NM_MAX_HID) return -3;
+  if (j->wide) {
+    // the general-shape path (nm_launch_wide): any width, latent <= 128; the plain cVAE / cVAE_multimodal model only
+    for (int i = 0; i < j->L; ++i)
+      if (j->H[i] < 1 || j->H[i] > NM_WIDE_MAX_WIDTH) return -4;
+    if (j->Z < 1 || j->Z > NM_WIDE_MAX_LATENT) return -5;
+    if (j->out_kind != 0 || j->n_private != 0 || j->tc_weight != 0.f || j->w_off >= 0 || j->reg_head || j->cls_classes > 0 ||
+        (j->M_enc != 0 && j->M_enc != j->M) || j->combine == NM_COMBINE_POE2V)
+      return -19;
+  } else {
   for (int i = 0; i < j->L; ++i)
     if (j->H[i] < 1 || j->H[i] > NM_MAX_WIDTH) return -4;
   if (j->Z < 1 || j->Z > NM_MAX_LATENT) return -5;
   if (j->Z + j->C > NM_MAX_WIDTH) return -6;
+  }
   if (j->combine < 0 || j->combine > NM_COMBINE_POE2V) return -9;
   if (j->out_kind < 0 || j->out_kind > 1 || j->n_private < 0 || j->n_private > j->Z) return -18;
   if (j->n_private > 0 && j->M_enc != 0 && j->M_enc != j->M) return -18;      // a private latent needs the modality's own encoder
   if (j->n_rows < 1 || j->loss_cap < 1 || j->eps_cap < 1) return -14;       // modulo divisors / batch count in the kernel
-  if (!j->wsh) return -15;
+  if (!j->wsh && !j->wide) return -15;
   for (int m = 0; m < j->M; ++m) {
     const nm_modality_t& md = j->mod[m];
     if (md.D < 1 || md.Kx % 32 != 0 || md.Kx < md.D + j->C + 1) return -7;
@@ -3311,6 +3353,7 @@ int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
 
 int64_t nm_workspace_bytes(const nm_job_t* j) {
   if (!j) return -1;
+  if (j->wide) return wide_ws_layout(j).total;
   int64_t b = ws_layout(j->M, j->L, j->Z).total;      // the head's region sits behind the trunk's
   int64_t hb = 0;
   if (j->reg_head) hb = ACT_BYTES;        // regression head: its first hidden activation, kept for the backward pass
@@ -3355,6 +3398,20 @@ static int launch_impl(const nm_job_t* jobs_dev, int n_jobs, int step0, int step
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(nm_step_kernel<false>, grid, block, SMEM_BYTES, st, jobs_dev, step0, steps_per_tile, flags, n_jobs, parts);
   }
+  return (int)hipGetLastError();
+}
+
+/* The general-shape path (csrc/nm_wide.inc): jobs with nm_job_t.wide = 1 -- hidden widths > 127, latent > 64 or
+ * latent + c_dim > 127 -- one workgroup per (job, tile), same launch contract as nm_launch. */
+int nm_launch_wide(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_per_tile, int n_tiles, int flags, void* stream) {
+  if (!jobs_dev) return -1;
+  if (n_jobs < 1 || steps_per_tile < 1 || n_tiles < 1 || step0 < 0) return -8;
+  if (n_tiles > 1 && (flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return -8;
+  hipError_t e = hipFuncSetAttribute((const void*)nm_wide_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+  if (e != hipSuccess) return (int)e;
+  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_EXPORT | NM_F_ZGIVEN);
+  hipLaunchKernelGGL(nm_wide_step_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step0,
+                     steps_per_tile, flags);
   return (int)hipGetLastError();
 }
 

@@ -177,6 +177,9 @@ class Job:
         lib = _lib.load()
         probe = _lib.NmJob()
         probe.M, probe.L, probe.Z = len(self.kmods), len(self.spec.hidden), self.spec.latent
+        probe.C, probe.wide = self.spec.net_c_dim, int(self.spec.wide)
+        for i, h in enumerate(self.spec.hidden):
+            probe.H[i] = h
         probe.cls_layers, probe.cls_classes = len(self.spec.classifier_layers), (self.spec.num_classes if self.spec.classifier_layers else 0)
         probe.reg_head = 1 if self.spec.kind == "regression" else 0
         probe.M_enc = self.spec.M
@@ -185,10 +188,13 @@ class Job:
             probe.mod[k].Kx = self.tables[m].Kx
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
         if self._wsh is None:
-            nb = int(lib.nm_fill_shadow(C.byref(probe)))
-            if nb < 0:
-                _lib.check(nb, "nm_fill_shadow")
-            self._wsh = torch.zeros(nb, dtype=torch.uint8, device=self.device)
+            if self.spec.wide:                       # the general-shape path reads the fp32 master: no shadow images
+                self._wsh = torch.zeros(256, dtype=torch.uint8, device=self.device)
+            else:
+                nb = int(lib.nm_fill_shadow(C.byref(probe)))
+                if nb < 0:
+                    _lib.check(nb, "nm_fill_shadow")
+                self._wsh = torch.zeros(nb, dtype=torch.uint8, device=self.device)
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
         self._version += 1
@@ -304,6 +310,7 @@ class Job:
         j.dephase = int(self.dephase_sleeps)
         k0 = self.tables[0].c_key
         j.shared_cov = 1 if (k0 is not None and all(t.c_key == k0 for t in self.tables)) else 0
+        j.wide = int(s.wide)
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
         j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
         j.adam_off = self.t - self.step
@@ -349,9 +356,10 @@ class Job:
             md.dloc_extra = self.dloc_extra[k].data_ptr() if self.dloc_extra[k] is not None else None
             md.dloc_rowcoef = self.dloc_rowcoef[k].data_ptr() if self.dloc_rowcoef[k] is not None else None
             j.rowcoef_out[k] = md.dloc_rowcoef
-        nb = int(_lib.load().nm_fill_shadow(C.byref(j)))           # shadow-image offsets of every modality
-        if nb != self._wsh.numel():
-            raise _lib.NmError(f"shadow size changed: {nb} vs {self._wsh.numel()} bytes")
+        if not s.wide:
+            nb = int(_lib.load().nm_fill_shadow(C.byref(j)))       # shadow-image offsets of every modality
+            if nb != self._wsh.numel():
+                raise _lib.NmError(f"shadow size changed: {nb} vs {self._wsh.numel()} bytes")
         _lib.check(_lib.load().nm_validate_job(C.byref(j)), "nm_validate_job")
         return j
 
@@ -388,6 +396,9 @@ class JobSet:
         if not jobs:
             raise ValueError("empty job set")
         self.jobs = list(jobs)
+        self.wide = bool(jobs[0].spec.wide)
+        if any(bool(j.spec.wide) != self.wide for j in jobs):
+            raise ValueError("a job set holds either fused-kernel shapes or general-shape (wide) models, not both")
         self.device = jobs[0].device
         self.lib = _lib.load()
         self._dev = None
@@ -451,6 +462,9 @@ class JobSet:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._dev = host.to(self.device)
             self._sig = sig
+        if self.wide:
+            for j in self.jobs:
+                j.shadow_dirty = False
         if any(j.shadow_dirty for j in self.jobs):
             _lib.check(self.lib.nm_sync_shadow(self._dev.data_ptr(), len(self.jobs), _stream_ptr(self.device)), "nm_sync_shadow")
             for j in self.jobs:
@@ -459,9 +473,9 @@ class JobSet:
 
     def _launch(self, step0, steps_per_tile, n_tiles, flags, scalar_tr=False):
         ptr = self._upload(n_tiles)
-        fn = self.lib.nm_launch_scalar_tr if scalar_tr else self.lib.nm_launch
+        fn = self.lib.nm_launch_wide if self.wide else (self.lib.nm_launch_scalar_tr if scalar_tr else self.lib.nm_launch)
         _lib.check(fn(ptr, len(self.jobs), int(step0), int(steps_per_tile), int(n_tiles), int(flags),
-                      _stream_ptr(self.device)), "nm_launch")
+                      _stream_ptr(self.device)), "nm_launch_wide" if self.wide else "nm_launch")
 
     def split_parts(self) -> int:
         """Workgroups per model for a training launch: the M modalities of a model as separate workgroups when the
@@ -469,7 +483,7 @@ class JobSet:
         forces one / insists on several."""
         M = len(self.jobs[0].kmods)
         mode = os.environ.get("NMHIP_SPLIT", "auto")
-        if mode == "0" or M < 2 or any(len(j.kmods) != M for j in self.jobs):
+        if mode == "0" or M < 2 or self.wide or any(len(j.kmods) != M for j in self.jobs):
             return 1
         if not hasattr(self, "_cus"):
             self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count

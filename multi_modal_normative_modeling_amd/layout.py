@@ -62,18 +62,28 @@ class ModelSpec:
         """DMVAE family: s_dim = c_dim (cVAE.py:1506), mu[:, :s_dim] of a [B, latent] tensor."""
         return min(self.c_dim, self.latent) if self.is_dm else 0
 
+    @property
+    def wide(self) -> bool:
+        """A shape beyond the fused step kernel's [256][128] tile (hidden width > 127, latent > 64, latent + c_dim > 127):
+        it runs through the general-shape path (nm_launch_wide, csrc/nm_wide.inc)."""
+        return (any(h > _lib.NM_MAX_WIDTH for h in self.hidden) or self.latent > _lib.NM_MAX_LATENT
+                or self.latent + self.net_c_dim > _lib.NM_MAX_WIDTH)
+
     def validate(self):
         n_dec = self.M * (2 if self.kind == "endtoend" else 1)
         if not (1 <= self.M <= _lib.NM_MAX_EXP) or n_dec > _lib.NM_MAX_MOD:
             raise ValueError(f"modalities must be 1..{_lib.NM_MAX_EXP} (and at most {_lib.NM_MAX_MOD} decoders), got {self.M}")
         if not (1 <= len(self.hidden) <= _lib.NM_MAX_HID):
             raise ValueError(f"hidden layers must be 1..{_lib.NM_MAX_HID}, got {len(self.hidden)}")
-        if any(h < 1 or h > _lib.NM_MAX_WIDTH for h in self.hidden):
-            raise ValueError(f"hidden widths must be 1..{_lib.NM_MAX_WIDTH}, got {list(self.hidden)}")
-        if not (1 <= self.latent <= _lib.NM_MAX_LATENT):
-            raise ValueError(f"latent_dim must be 1..{_lib.NM_MAX_LATENT}, got {self.latent}")
-        if self.latent + self.net_c_dim > _lib.NM_MAX_WIDTH:
-            raise ValueError(f"latent_dim + c_dim must be <= {_lib.NM_MAX_WIDTH}")
+        if any(h < 1 or h > _lib.NM_WIDE_MAX_WIDTH for h in self.hidden):
+            raise ValueError(f"hidden widths must be 1..{_lib.NM_WIDE_MAX_WIDTH}, got {list(self.hidden)}")
+        if not (1 <= self.latent <= _lib.NM_WIDE_MAX_LATENT):
+            raise ValueError(f"latent_dim must be 1..{_lib.NM_WIDE_MAX_LATENT}, got {self.latent}")
+        if self.wide and self.kind not in ("single", "multimodal"):
+            # (the head models, the DMVAE family and mvtCAE run on the fused kernel only: DESIGN.md section 6)
+            raise ValueError(f"model kind '{self.kind}' is limited to hidden widths <= {_lib.NM_MAX_WIDTH}, latent_dim <= "
+                             f"{_lib.NM_MAX_LATENT} and latent_dim + c_dim <= {_lib.NM_MAX_WIDTH}; got hidden {list(self.hidden)}, "
+                             f"latent {self.latent}, c_dim {self.net_c_dim}")
         if self.is_dm and len(self.hidden) != 2:
             raise ValueError("the DMVAE family has exactly two hidden layers (hidden_dims[0], hidden_dims[1])")
         if len(self.classifier_layers) > _lib.NM_MAX_CLS or any(w < 1 or w > 128 for w in self.classifier_layers):

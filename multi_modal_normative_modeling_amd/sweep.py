@@ -480,6 +480,8 @@ def build_parser():
     ap.add_argument("--save-models", action="store_true",
                     help="write <out-dir>/<resource>/<procedure>/<fold:03d>/cVAE_model_state.pt (what the `test` subcommand loads)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend when WORLD_SIZE > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 (with --backend gloo)")
     return ap
 
 
@@ -504,6 +506,8 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
     use_gpu = torch.cuda.is_available() and _run_cells is None
+    if args.share_device:
+        local_rank = 0
     device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
@@ -537,8 +541,13 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     # run_cells writes a cell's CSVs into <out>/<procedure>/ when procedures share modalities (per_procedure_dirs)
     kw = {} if _run_cells is not None else {"per_procedure_dirs": True, "model": args.model,
                                             "models_dir": out_dir if (args.save_models and out_dir is not None) else None}
+    t_rank = time.perf_counter()
     local = runner(cohort, mine, args.n_splits, args.epochs, device, out_dir=None if args.no_csv else out_dir,
                    lr=args.base_learning_rate, oversample_percentage=oversample, hidden=hidden, latent=latent, **kw)
+    # the sweep is a STRONG-scaling job (a fixed grid of cells dealt over the ranks): what a rank got and how long it
+    # took is what makes an N-GPU run of a small grid readable (20 cells over 8 GPUs = 3/3/3/3/2/2/2/2)
+    print(f"[sweep rank {rank}/{world}] cells {len(mine)} of {len(cells)} (cost share "
+          f"{sum(c.cost for c in mine) / max(sum(c.cost for c in cells), 1e-9):.3f})  wall {time.perf_counter() - t_rank:.2f} s", flush=True)
     max_rows = (len(cells) + world - 1) // world
     table = gather_metrics(local.to(device) if (world > 1 and dist.get_backend() == "nccl") else local, max_rows)
     if rank == 0:

@@ -498,10 +498,12 @@ def loss_regression(spec: Spec, xes, fwd, true_fi, lambda_reg: float = 1.0):
 # ----------------------------------------------------------------------------------------
 # A13  cVAE_multimodal_endtoend        (cVAE.py:2004-2207)
 # ----------------------------------------------------------------------------------------
-def classifier_fwd(P, spec: Spec, z, training: bool, bn_stats: Optional[dict] = None):
-    """Classifier (cVAE.py:2004-2018): (Linear - BatchNorm1d - ReLU - Dropout)* - Linear.  Dropout is the
-    identity here (rate 0 in training parity runs, eval otherwise).  In training mode BatchNorm uses the
-    batch statistics; in eval mode the running statistics passed in `bn_stats`."""
+def classifier_fwd(P, spec: Spec, z, training: bool, bn_stats: Optional[dict] = None, drop_masks=None, drop_p: float = 0.0):
+    """Classifier (cVAE.py:2004-2018): (Linear - BatchNorm1d - ReLU - Dropout)* - Linear.  Dropout (nn.Dropout in
+    train mode, :2012): `drop_masks` = one [B, width] 0/1 keep mask per block (torch draws it from the global
+    generator; parity runs inject the mask the kernel used), kept activations scaled by 1 / (1 - drop_p); None: the
+    identity (rate 0, or eval).  In training mode BatchNorm uses the batch statistics; in eval mode the running
+    statistics passed in `bn_stats`."""
     h = z
     li = 0
     for _ in range(len(spec.classifier_layers)):
@@ -514,12 +516,14 @@ def classifier_fwd(P, spec: Spec, z, training: bool, bn_stats: Optional[dict] = 
             h = torch.nn.functional.batch_norm(h, bn_stats[q + ".running_mean"], bn_stats[q + ".running_var"],
                                                P[q + ".weight"], P[q + ".bias"], False, 0.1, 1e-5)
         h = torch.relu(h)
+        if training and drop_masks is not None and drop_p > 0.0:
+            h = h * drop_masks[li // 4].to(h.dtype) / (1.0 - drop_p)
         li += 4
     p = f"classifier.classifier.{li}"
     return linear(h, P[p + ".weight"], P[p + ".bias"])
 
 
-def forward_endtoend(P, spec: Spec, xes, cs, eps, training: bool = True, bn_stats=None):
+def forward_endtoend(P, spec: Spec, xes, cs, eps, training: bool = True, bn_stats=None, drop_masks=None, drop_p: float = 0.0):
     """cVAE.py:2106-2123: shared encoders -> PoE WITHOUT the single-expert bypass (cVAE.py:2083-2090)
     -> z -> health and disease decoder banks + classifier(z)."""
     enc = [encoder_fwd(P, spec, m, xes[m], cs[m]) for m in range(spec.M)]
@@ -535,7 +539,7 @@ def forward_endtoend(P, spec: Spec, xes, cs, eps, training: bool = True, bn_stat
         ld, sd = decoder_fwd(P, spec, m, z, cs[m], "disease")
         locs_h.append(lh); locs_d.append(ld); scales_h.append(sh); scales_d.append(sd)
     return {"locs_h": locs_h, "locs_d": locs_d, "scales_h": scales_h, "scales_d": scales_d, "mu": mu, "logvar": logvar,
-            "z": z, "logits": classifier_fwd(P, spec, z, training, bn_stats)}
+            "z": z, "logits": classifier_fwd(P, spec, z, training, bn_stats, drop_masks, drop_p)}
 
 
 def loss_endtoend(spec: Spec, xes, fwd, labels, margin=1.0, weightcontrastive=0.1, weight_kl=0.1, weight_rec=0.1):

@@ -359,6 +359,45 @@ def case_endtoend(ref, name, dims, c_dim, hidden, Z, B, layers, n_steps, seed, m
     print("wrote", name, out["loss0"])
 
 
+def case_fusion_ops(ref, name, M, B, Z, seed):
+    """The public expert-fusion methods of the hot-path classes on fixed inputs: cVAE_multimodal.combine_latent
+    (cVAE.py:1144-1164) for the four combiners and the M = 1 bypass, product_of_experts / mixture_of_experts /
+    mixture_of_product_of_experts (:1118-1126), the same on cVAE_multimodal_regression (:2265-2307), mvtCAE's
+    (ProductOfExperts2 on what it is given, the 1e-6 clamp, total_correlation :1782-1869) and mmJSD.combine_latent (:1399-1402)."""
+    g = torch.Generator().manual_seed(seed)
+    mus = torch.randn(M, B, Z, generator=g)
+    variances = torch.exp(0.7 * torch.randn(M, B, Z, generator=g))
+    alpha = torch.randn(M, generator=g)
+    out = {"meta": np.array([M, 0, Z, B, 0]), "mus": mus.numpy(), "variances": variances.numpy(), "alpha": alpha.numpy()}
+    dims = [5] * M
+    for cname in ("cVAE_multimodal", "cVAE_multimodal_regression", "mvtCAE"):
+        model = getattr(ref, cname)(dims, [8, 8], Z, 2, modalities=M)
+        with torch.no_grad():
+            for m in range(M):
+                model.alpha_m_list[m].copy_(alpha[m:m + 1])
+            for comb in ("poe", "gpoe", "moe", "mopoe"):
+                mu, var = model.combine_latent(mus, variances, comb)
+                out[f"{cname}.combine_latent.{comb}.mu"], out[f"{cname}.combine_latent.{comb}.var"] = mu.numpy(), var.numpy()
+            for meth in ("product_of_experts", "mixture_of_experts", "mixture_of_product_of_experts"):
+                mu, var = getattr(model, meth)(mus, variances)
+                out[f"{cname}.{meth}.mu"], out[f"{cname}.{meth}.var"] = mu.numpy(), var.numpy()
+            if cname != "mvtCAE":
+                mu, var = model.combine_latent(mus[:1], variances[:1], "gpoe")          # single-expert bypass
+                out[f"{cname}.combine_latent.single.mu"], out[f"{cname}.combine_latent.single.var"] = mu.numpy(), var.numpy()
+            else:
+                small = 1e-8 * variances                                                 # the clamp at 1e-6
+                mu, var = model.combine_latent(mus, small, "moe")
+                out["mvtCAE.combine_latent.clamped.mu"], out["mvtCAE.combine_latent.clamped.var"] = mu.numpy(), var.numpy()
+                tc = model.total_correlation(mus, mus.mean(0))
+                out["mvtCAE.total_correlation"] = np.asarray(float(tc), dtype=np.float32)
+    jsd = ref.mmJSD(dims, [8, 8], Z, 2, modalities=M)
+    with torch.no_grad():
+        mu, var = jsd.combine_latent(mus, torch.log(variances))
+    out["mmJSD.combine_latent.mu"], out["mmJSD.combine_latent.var"] = mu.numpy(), var.numpy()
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(f"[golden] {name}: {len(out)} arrays")
+
+
 def case_csv_headers(name):
     """G7/G8: layout facts of the committed CSV artefacts (first line + IID column only, plus a
     known-answer slice of one (x, x_hat, err_roi, err) quintuple)."""
@@ -400,7 +439,8 @@ def main():
         import builtins
         keep = lambda fn: (lambda r, name, *a, **k: fn(r, name, *a, **k) if name in only else None)
         g = globals()
-        for fname in ("case_multimodal", "case_single", "case_deviation", "case_regression", "case_endtoend", "case_dm", "case_mvt"):
+        for fname in ("case_multimodal", "case_single", "case_deviation", "case_regression", "case_endtoend", "case_dm", "case_mvt",
+                      "case_fusion_ops"):
             g[fname] = keep(g[fname])
         orig_csv = g["case_csv_headers"]
         g["case_csv_headers"] = lambda name: orig_csv(name) if name in only else None
@@ -418,6 +458,7 @@ def main():
     case_single(ref, "single_small", 37, 7, (24, 16), 6, 19, seed=105)
     case_deviation(ref, "dev_small", (23, 17, 29), 5, (24, 16), 6, 40, "gpoe", seed=106)
     case_csv_headers("csv_layouts")
+    case_fusion_ops(ref, "fusion_ops", 3, 19, 6, seed=120)
     case_regression(ref, "reg3_gpoe", (23, 17, 29), 2, (24, 16), 6, 32, "gpoe", 3, seed=107)
     case_endtoend(ref, "e2e3", (23, 17, 29), 7, (24, 16), 8, 32, (16, 8), 3, seed=108)
     # baseline zoo: mmJSD (cVAE.py:1354-1448) = product of experts without the single-expert

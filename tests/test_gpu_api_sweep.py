@@ -911,3 +911,198 @@ def test_non_finite_loss_is_detected():
     with pytest.raises(nm._lib.NmError, match="job 1"):
         js.assert_finite()
     nm.JobSet([good]).assert_finite()
+
+
+@pytest.mark.gpu
+def test_expert_fusion_methods_match_reference_golden():
+    """combine_latent / product_of_experts / mixture_of_experts / mixture_of_product_of_experts of the drop-in classes
+    (nm_combine_latent), mvtCAE's variants + total_correlation and mmJSD.combine_latent against tests/golden/fusion_ops.npz,
+    which oracle/gen_golden.py: case_fusion_ops wrote from the reference classes (cVAE.py:1118-1164, 1399-1402, 1782-1866,
+    2265-2307).  Elementwise fp32: 2e-6 relative."""
+    import numpy as np
+    from tests.golden_util import GOLDEN
+    import multi_modal_normative_modeling_amd.api as api
+    g = np.load(GOLDEN / "fusion_ops.npz")
+    mus, variances, alpha = torch.from_numpy(g["mus"]), torch.from_numpy(g["variances"]), torch.from_numpy(g["alpha"])
+    M, Z = int(mus.shape[0]), int(mus.shape[2])
+
+    def close(a, key):
+        ref = torch.from_numpy(np.asarray(g[key]))
+        a = a.detach().cpu().reshape(ref.shape)
+        assert torch.allclose(a, ref, rtol=2e-6, atol=1e-7), (key, float((a - ref).abs().max()))
+
+    for cname in ("cVAE_multimodal", "cVAE_multimodal_regression", "mvtCAE"):
+        model = getattr(api, cname)([5] * M, [8, 8], Z, 2, modalities=M)
+        sd = model.state_dict()
+        for m in range(M):
+            sd[f"alpha_m_list.{m}"] = alpha[m:m + 1].clone()
+        model.load_state_dict(sd)
+        for comb in ("poe", "gpoe", "moe", "mopoe", "GPoE"):
+            mu, var = model.combine_latent(mus, variances, comb)
+            close(mu, f"{cname}.combine_latent.{comb.lower()}.mu"); close(var, f"{cname}.combine_latent.{comb.lower()}.var")
+        for meth in ("product_of_experts", "mixture_of_experts", "mixture_of_product_of_experts"):
+            mu, var = getattr(model, meth)(mus, variances)
+            close(mu, f"{cname}.{meth}.mu"); close(var, f"{cname}.{meth}.var")
+        with pytest.raises(ValueError):
+            model.combine_latent(mus, variances, "nope")
+        if cname != "mvtCAE":
+            mu, var = model.combine_latent(mus[:1], variances[:1], "gpoe")
+            close(mu, f"{cname}.combine_latent.single.mu"); close(var, f"{cname}.combine_latent.single.var")
+        else:
+            mu, var = model.combine_latent(mus, 1e-8 * variances, "moe")
+            close(mu, "mvtCAE.combine_latent.clamped.mu"); close(var, "mvtCAE.combine_latent.clamped.var")
+            tc = model.total_correlation(mus, mus.mean(0))
+            ref = float(g["mvtCAE.total_correlation"])
+            assert abs(float(tc) - ref) <= 2e-6 * abs(ref), (float(tc), ref)
+    jsd = api.mmJSD([5] * M, [8, 8], Z, 2, modalities=M)
+    mu, var = jsd.combine_latent(mus, torch.log(variances))
+    close(mu, "mmJSD.combine_latent.mu"); close(var, "mmJSD.combine_latent.var")
+    e2e = api.cVAE_multimodal_endtoend([5] * M, [8, 8], Z, 2, modalities=M, classifier_layers=[8])
+    mu, lv = e2e.combine_latent(mus, torch.log(variances))           # cVAE.py:2083-2090 = PoE, log variance back
+    close(mu, "cVAE_multimodal.product_of_experts.mu")
+    ref_lv = torch.log(torch.from_numpy(g["cVAE_multimodal.product_of_experts.var"]))
+    assert torch.allclose(lv.cpu(), ref_lv, rtol=1e-5, atol=2e-6)
+
+
+def _kernel_dropout_keep(seed, step, layer, rows, width, p):
+    """The keep mask the classifier head draws (csrc/nmhip.hip: uniform4_ctr -- one splitmix64 hash per (step, block,
+    row, group of 4 features), 16 bits per feature, keep <=> u >= p), recomputed on the host."""
+    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        r = np.arange(rows, dtype=np.uint64)[:, None]
+        fg = np.arange((width + 3) // 4, dtype=np.uint64)[None, :]
+        x = (np.uint64(seed) ^ np.uint64(0xC1A551F1E5) ^ (np.uint64(step) << np.uint64(32)) ^ (np.uint64(layer) << np.uint64(28))
+             ^ (r << np.uint64(8)) ^ fg) & M64
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        h = x ^ (x >> np.uint64(31))
+    u = np.stack([((h >> np.uint64(16 * i)) & np.uint64(0xFFFF)).astype(np.float32) / 65536.0 for i in range(4)], axis=-1)
+    u = u.reshape(rows, -1)[:, :width]
+    return torch.from_numpy((u >= np.float32(p)).astype(np.float32))
+
+
+@pytest.mark.parametrize("dims,hidden,cdim,B,p", [([60, 45, 70], [40, 32], 5, 200, 0.5), ([379, 379, 379], [110, 110], 29, 256, 0.5),
+                                                   ([60, 45, 70], [40, 32], 5, 64, 0.25)])
+def test_classifier_dropout_parity_vs_oracle(dims, hidden, cdim, B, p):
+    """Config 5 with the classifier's Dropout ON (the script's dropout_rate = 0.5, multimodal_kfold_cvae_nmpmcont.py:257-268;
+    Classifier: cVAE.py:2004-2018).  torch's own mask comes from the global Philox stream and is not reproducible, so the
+    comparison injects the kernel's mask into the oracle: the mask is recomputed on the host from the kernel's counter
+    hash, and logits, cross entropy, hinge and every gradient of the model are held to the oracle with that mask; plus
+    the properties a dropout layer must have -- keep fraction ~ 1 - p, kept activations scaled by 1 / (1 - p) (checked
+    through the logits: they match an oracle that scales, and do not match one that does not)."""
+    Z, layers = 64, [128, 64, 32]
+    torch.manual_seed(11)
+    model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
+                                        dropout_rate=p, num_classes=2)
+    model.to(DEV)
+    model.train()
+    g = torch.Generator().manual_seed(23)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.rand(B, cdim, generator=g)
+    labels = (torch.rand(B, generator=g) < 0.4).long()
+    eps = torch.randn(B, Z, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model._eps_override = eps
+    fwd = model.forward([x.to(DEV) for x in xes], [c.to(DEV)] * 3)
+    loss = model.loss_function(xes, fwd, labels.to(DEV), margin=0.5, weightcontrastive=0.7)
+    model.optimizer.zero_grad()
+    loss["total_loss"].backward()
+    got = {n: q.grad.detach().cpu() for n, q in model.named_parameters() if q.grad is not None}
+
+    masks = [_kernel_dropout_keep(model._job.seed, 0, li, B, w, p) for li, w in enumerate(layers)]
+    for mk in masks:                                   # keep fraction: binomial, 5 sigma
+        n = mk.numel()
+        assert abs(float(mk.mean()) - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n), float(mk.mean())
+    spec = R.Spec(dims, hidden, Z, cdim, True, kind="endtoend", classifier_layers=layers)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        of = R.forward_endtoend(P, spec, xes, [c] * 3, eps, training=True, drop_masks=masks, drop_p=p)
+        ol = R.loss_endtoend(spec, xes, of, labels, margin=0.5, weightcontrastive=0.7)
+        ol["total_loss"].backward()
+        with torch.no_grad():                          # the same masks WITHOUT the 1 / (1 - p) scaling, and no dropout at all
+            unscaled = R.classifier_fwd(P, spec, of["z"], True, None, [mk * (1 - p) for mk in masks], p)
+            nodrop = R.classifier_fwd(P, spec, of["z"], True)
+    finally:
+        R.set_operand_rounding("fp32")
+    e_ok = rel_err(fwd["logits"].cpu(), of["logits"].detach())
+    assert e_ok < 2e-2, e_ok
+    assert rel_err(fwd["logits"].cpu(), unscaled) > 5 * e_ok and rel_err(fwd["logits"].cpu(), nodrop) > 5 * e_ok
+    for k in ("classification_loss", "contrastive_loss", "total_loss"):
+        assert abs(float(loss[k]) - float(ol[k])) <= 5e-3 * abs(float(ol[k])) + 1e-5, k
+    for k, v in P.items():
+        if v.grad is None or k.endswith(tuple(f"classifier.{4 * i}.bias" for i in range(len(layers)))):
+            continue                                  # Linear biases ahead of BatchNorm: exactly zero gradient in exact arithmetic
+        a, r = got[k].flatten().float(), v.grad.flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+        rl2 = float((a - r).norm() / r.norm())
+        assert cos > 0.99 and rl2 < 0.15, (k, cos, rl2)
+
+
+def test_split_handoff_timeout_is_reported():
+    """A part of a split launch that never arrives (NM_F_FAULT_INJECT: part 1 of every job leaves at once) makes the
+    others' hand-off time out: they leave the launch, the job's error word is set, and the host raises NmError at the next
+    point that reads results or launches again (JobSet.check_split_errors) instead of training on stale statistics."""
+    from multi_modal_normative_modeling_amd import _lib
+    g = Golden("mm3_gpoe")
+    tables = [nm.Table(g.xs(0)[m], g.t("c")[0], DEV) for m in range(g.M)]
+    job = nm.Job(nm.ModelSpec(g.dims, g.hidden, g.Z, g.c_dim), tables, combine="gpoe", state=g.weights("w0"))
+    js = nm.JobSet([job])
+    p0 = job.params.clone()
+    ptr = js._upload(1)
+    flags = _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | _lib.NM_F_FAULT_INJECT
+    _lib.check(js.lib.nm_launch_split(ptr, 1, g.M, 0, 2, flags, torch.cuda.current_stream().cuda_stream), "nm_launch_split")
+    js._split_pending = True
+    torch.cuda.synchronize()
+    with pytest.raises(nm.NmError, match="hand-off"):
+        js.assert_finite()
+    js.check_split_errors()                            # read and cleared: a second check passes
+    # the sound path on the same set afterwards: a normal split launch completes and reports nothing
+    job.params.copy_(p0); job.adam_m.zero_(); job.adam_v.zero_(); job.params_changed()
+    js.train(2, split=True)
+    torch.cuda.synchronize()
+    js.assert_finite()
+    assert not torch.equal(job.params, p0)
+
+
+def _run_two_ranks(cmd_tail, timeout=600):
+    """Two fresh processes under torch.distributed.run (never an exec of this pytest process, which already holds the GPU),
+    gloo for the control plane, both ranks on cuda:0: the multi-rank branch of bench.py / the sweep CLI with device tensors."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29417"] + cmd_tail
+    return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_two_ranks_share_device():
+    """bench.py --gpus 2 as the driver launches it (one process per rank), rehearsed on one GPU: barrier, max-over-ranks
+    timing and the final all_gather of the metric table with both ranks' rows."""
+    import json
+    r = _run_two_ranks(["bench.py", "--gpus", "2", "--backend", "gloo", "--share-device", "--jobs", "8", "--steps", "4", "--warmup", "1",
+                        "--repeats", "2", "--min-warm-s", "0", "--cpu-budget", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["metric_table_rows_gathered"] == 16          # 8 models from each of the two ranks
+    assert out["value"] > 0 and "cpu_baseline" not in out             # the CPU leg runs at N = 1 only
+
+
+def test_sweep_cli_two_ranks_share_device():
+    """The sharded sweep entry with two ranks: every rank trains its cells on the GPU, rank 0 receives the gathered
+    metric table with every cell exactly once and prints the per-rank bookkeeping."""
+    with tempfile.TemporaryDirectory() as d:
+        r = _run_two_ranks(["-m", "multi_modal_normative_modeling_amd.sweep", "-R", "HCPimage", "-P", "SM-T1w_sMRI", "SE-gPoE",
+                            "-E", "1", "-K", "3", "--subjects", "300", "--out-dir", d, "--no-csv", "--backend", "gloo", "--share-device"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        df = pd.read_csv(f"{d}/HCPimage/sweep_metrics.csv")
+        assert sorted(df["job_id"].astype(int).tolist()) == list(range(6))
+        assert np.isfinite(df["final_total_loss"]).all() and df["roc_auc"].between(0, 1).all()
+        ranks = [l for l in r.stdout.splitlines() if l.startswith("[sweep rank")]
+        assert len(ranks) == 2 and all("cells 3 of 6" in l for l in ranks), ranks
