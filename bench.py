@@ -37,12 +37,13 @@ sys.path.insert(0, str(ROOT))
 def kernel_src_sha16() -> str:
     """Identity of the kernel source the loaded library was built from (bench <-> PMC record match)."""
     h = hashlib.sha256()
-    for p in (ROOT / "multi_modal_normative_modeling_amd" / "csrc" / "nmhip.hip", ROOT / "include" / "nmhip.h"):
+    csrc = ROOT / "multi_modal_normative_modeling_amd" / "csrc"
+    for p in (csrc / "nmhip.hip", csrc / "nm_wide.inc", ROOT / "include" / "nmhip.h"):
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
 
 
-def device_record(torch, nm, js, dev):
+def device_record(torch, nm, js, dev, trace=True):
     """Clocks of this run: what the runtime reports, what sysfs shows (where readable), and the shader clock the step
     kernel itself saw -- cycles of one wave (clock64) over the same interval on the constant 100 MHz counter
     (s_memrealtime), from a short NM_F_TRACE launch after the timed regions (MI355X_MICROARCH.md, DVFS give-back)."""
@@ -52,6 +53,8 @@ def device_record(torch, nm, js, dev):
     rec = {"name": prop.name, "cus": prop.multi_processor_count,
            "clock_rate_khz": getattr(prop, "clock_rate", None), "memory_clock_rate_khz": getattr(prop, "memory_clock_rate", None)}
     try:
+        if not trace:
+            raise RuntimeError("skipped (--lean)")
         lib = _lib.load()
         buf, wg = (C.c_ulonglong * 512)(), (C.c_ulonglong * 1024)()
         lib.nm_trace_read(buf, 1)
@@ -101,6 +104,9 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=128,
                     help="train steps inside one persistent launch (the timed K steps run as ceil(K / this) launches)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
+    ap.add_argument("--lean", action="store_true",
+                    help="only the warm-up and the timed regions: no small-sweep legs, no traced launch for the device record "
+                         "(profiler passes: every nm_step_kernel dispatch of the run is then one of the K-step launches)")
     ap.add_argument("--small-sweep", type=int, default=1,
                     help="1: also time the metric's literal shape -- 5 folds -- and the reference's 20-cell sweep and one model "
                          "alone (own short legs after the timed region, rank 0 at N = 1; 0 = skip)")
@@ -246,11 +252,11 @@ def main():
 
     # ---- what the record needs to explain box-to-box differences: the clocks this run saw ----
     if rank == 0:
-        out["device"] = device_record(torch, nm, js, dev)
+        out["device"] = device_record(torch, nm, js, dev, trace=not args.lean)
 
     # ---- small sweeps: the metric's literal shape (5 folds) and the reference's real grid (20 cells), one model alone ----
     # (own short legs OUTSIDE the timed region above; the models run as one workgroup per modality: nm_launch_split)
-    if world == 1 and args.small_sweep and args.procedure == "SE-gPoE":
+    if world == 1 and args.small_sweep and not args.lean and args.procedure == "SE-gPoE":
         small = {}
         pool = workload.build_sweep_jobs(cohort, args.procedure, 5, 26, dev, seed0=10_000)
         for name, n, lo in (("jobs5", 5, 0), ("jobs20", 20, 5), ("single_model", 1, 25)):

@@ -54,7 +54,8 @@ def _probe(M=1, L=2, Z=10, C_=29, H=(110, 110), D=379):
 def test_validate_job_limits(lib):
     assert lib.nm_validate_job(C.byref(_probe())) == 0
     assert lib.nm_validate_job(C.byref(_probe(M=5))) == -2
-    assert lib.nm_validate_job(C.byref(_probe(L=4, H=(8, 8, 8)))) == -3
+    assert lib.nm_validate_job(C.byref(_probe(L=9, H=(8, 8, 8)))) == -3
+    assert lib.nm_validate_job(C.byref(_probe(L=5, H=(90, 90, 90, 90, 90)))) == 0     # "-H 90 90 90 90 90 10", commands_list9_endtoend.sh:24
     assert lib.nm_validate_job(C.byref(_probe(H=(128, 110)))) == -4
     assert lib.nm_validate_job(C.byref(_probe(Z=65))) == -5
     assert lib.nm_validate_job(C.byref(_probe(Z=64, C_=64))) == -6
@@ -72,6 +73,18 @@ def test_validate_job_limits(lib):
     bad = _probe()
     bad.mod[0].enc_w[0] = 8                                     # weight matrices start on a tile boundary
     assert lib.nm_validate_job(C.byref(bad)) == -10
+    # the general-shape path (nm_job_t.wide): the widths / latents of the reference's sweeps the fused tile cannot hold
+    for kw in (dict(H=(1024, 512, 256), L=3, Z=32), dict(H=(300, 300), Z=30), dict(H=(110, 110), Z=100), dict(H=(2048,), L=1, Z=10)):
+        j = _probe(**kw)
+        assert lib.nm_validate_job(C.byref(j)) in (-4, -5, -6)      # not a fused-kernel shape ...
+        j.wide, j.w_off = 1, -1
+        j.wsh = None                                                # ... and the wide path needs no shadow images
+        assert lib.nm_validate_job(C.byref(j)) == 0
+        assert lib.nm_workspace_bytes(C.byref(j)) > 0
+    j = _probe(H=(300, 300), Z=30)
+    j.wide, j.reg_head, j.w_off = 1, 1, -1
+    assert lib.nm_validate_job(C.byref(j)) == -19                   # head models stay on the fused kernel
+    assert lib.nm_validate_job(C.byref(_probe(H=(5000, 10)))) == -4
 
 
 def test_shadow_layout(lib):
@@ -134,7 +147,14 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_spec_limits_raise():
+    assert nm.ModelSpec([10], [200], 5, 2).wide and not nm.ModelSpec([10], [127], 64, 29).wide
+    assert nm.ModelSpec([10], [110, 110], 100, 29).wide                      # latent + c_dim > 127
+    nm.ParamLayout(nm.ModelSpec([10], [200], 5, 2))                           # general-shape path: constructs
     with pytest.raises(ValueError):
-        nm.ParamLayout(nm.ModelSpec([10], [200], 5, 2))
+        nm.ParamLayout(nm.ModelSpec([10], [5000], 5, 2))
+    with pytest.raises(ValueError):
+        nm.ParamLayout(nm.ModelSpec([10], [20], 129, 2))
+    with pytest.raises(ValueError):                                           # head models stay on the fused kernel's shapes
+        nm.ParamLayout(nm.ModelSpec([10, 10], [200], 5, 2, True, "regression"))
     with pytest.raises(ValueError):
         nm.ParamLayout(nm.ModelSpec([10] * 5, [20], 5, 2))

@@ -7,7 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $OUT/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --repeats 1 --min-warm-s 0 "$@" > $OUT/$ctr.log 2>&1 || true
+  rocprofv3 --pmc $ctr --output-format csv -d $OUT/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --lean --repeats 1 --min-warm-s 0 "$@" > $OUT/$ctr.log 2>&1 \
+    || { echo "rocprofv3 --pmc $ctr failed:"; tail -5 $OUT/$ctr.log; exit 1; }
 done
 python3 - "$OUT" "$TAG" "$@" <<'PY'
 import csv, glob, collections, json, sys, hashlib
@@ -28,9 +29,12 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 n += 1; s += float(row["Counter_Value"])
     tot[ctr] = (n, s)
     print(ctr, "nm_step_kernel dispatches", n, "sum (KB)", s)
+if tot["FETCH_SIZE"][0] == 0 or tot["WRITE_SIZE"][0] == 0 or tot["FETCH_SIZE"][0] != tot["WRITE_SIZE"][0]:
+    sys.exit(f"no / unequal nm_step_kernel dispatches in the counter passes ({tot}): no record written")
 job_steps = jobs * (steps + warm)                 # every dispatch of the run: warm-up + one timed region
 h = hashlib.sha256()
-for p in (root / "multi_modal_normative_modeling_amd" / "csrc" / "nmhip.hip", root / "include" / "nmhip.h"):
+csrc = root / "multi_modal_normative_modeling_amd" / "csrc"
+for p in (csrc / "nmhip.hip", csrc / "nm_wide.inc", root / "include" / "nmhip.h"):
     h.update(p.read_bytes())
 fetch = tot["FETCH_SIZE"][1] * 1024 / job_steps
 write = tot["WRITE_SIZE"][1] * 1024 / job_steps

@@ -12,7 +12,7 @@ G3="TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"
 i=0
 for G in "$G1" "$G2" "$G3"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --steps 32 --warmup 4 --repeats 1 --min-warm-s 0 --steps-per-launch 32 > $OUT/g$i.log 2>&1 || true
+  rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --lean --steps 32 --warmup 4 --repeats 1 --min-warm-s 0 --steps-per-launch 32 > $OUT/g$i.log 2>&1 || true
 done
 python3 - <<PY
 import csv, glob, collections
