@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=128,
                     help="train steps inside one persistent launch (the timed K steps run as ceil(K / this) launches)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
+    ap.add_argument("--placement", choices=["none", "rank"], default="none",
+                    help="job -> fold map: none = fold j mod 5; rank = the models of a fold sit on the same XCD(s) and share "
+                         "its L2 copy of the fold's ROI tables (speed / traffic only)")
     ap.add_argument("--lean", action="store_true",
                     help="only the warm-up and the timed regions: no small-sweep legs, no traced launch for the device record "
                          "(profiler passes: every nm_step_kernel dispatch of the run is then one of the K-step launches)")
@@ -148,7 +151,8 @@ def main():
     # ---- workload: resident in HBM before timing ----
     cohort = prep.synthetic_cohort(n=args.subjects, d=379)
     log("synthetic cohort ready")
-    jobs = workload.build_sweep_jobs(cohort, args.procedure, 5, args.jobs, dev, seed0=rank * args.jobs)
+    jobs = workload.build_sweep_jobs(cohort, args.procedure, 5, args.jobs, dev, seed0=rank * args.jobs,
+                                     xcd_affinity={"none": False, "rank": "rank"}[args.placement])
     log(f"{len(jobs)} jobs resident on {dev}")
     js = nm.JobSet(jobs)
     spec = jobs[0].spec

@@ -536,8 +536,9 @@ __device__ __forceinline__ void wblk_store(const Ctx& c, const WBlk<NR>& s, __bf
 // then the z columns from the latent workspace.
 // (DMVAE family: the last S of the Z latent columns are the modality's private latent = columns [0, S) of its own
 // encoder's mu, `priv`, taken as they are)
+// (zsrc != nullptr: the z columns come from LDS, bf16 [256][32] -- fwd_heads' in-register draw)
 __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_modality_t& md, gcf32 mu_j, gcf32 es, int Z,
-                                         int C, int Zs, int S, gcf32 priv) {
+                                         int C, int Zs, int S, gcf32 priv, const __bf16* zsrc = nullptr) {
   const int wz = wpad(Z + C);
   const float rz = 1.0f / (float)Z;
   const GAS uint16_t* cz = asg(md.cz);
@@ -566,6 +567,14 @@ __device__ __forceinline__ void build_zc(const Ctx& c, __bf16* dst, const nm_mod
     }
   }
   const int Zc = Z - S;                              // shared columns first, then the private ones
+  if (zsrc) {
+#pragma unroll 4
+    for (int e = c.tid; e < ROWS * Z; e += WG) {
+      int r = idiv(e, Z, rz), k = e - r * Z;
+      dst[r * LDP + k] = zsrc[r * 32 + k];
+    }
+    return;
+  }
 #pragma unroll 4
   for (int e = c.tid; e < ROWS * Z; e += WG) {
     int r = idiv(e, Z, rz), k = e - r * Z;
@@ -724,8 +733,13 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const GAS char* x
 // ---- GEMM phase: encoder heads, P (= last hidden) -> fp32 mu / logvar in the workspace --------
 // Heads image: rows [0, Z) = enc_mean_layer, rows [Zs, Zs + Z) = enc_logvar_layer, zeros elsewhere; the vector
 // piece holds the biases at the same row indices.
+// `zdst` != nullptr (forward-only launches of a single-expert model, the deviation pass): the latent draw is made right
+// here from the accumulators -- z = mu + eps exp(logvar / 2) with the exp -> log round trip of cVAE.py:1175-1178 -- and
+// goes to LDS as bf16 [256][32] (the decoder's input operand); nothing is stored to the workspace, the fusion phase and
+// its two hand-offs through global memory are skipped.  kl_out receives this thread's share of the KL sum.
 __device__ __forceinline__ void fwd_heads(const Ctx& cc, int half, const Next& nx, int Z, int K, gf32 mu_out, gf32 lv_out,
-                                          int Zs, int younger) {
+                                          int Zs, int younger, __bf16* zdst = nullptr, int step = 0, bool pair_draw = false,
+                                          float* kl_out = nullptr) {
   Ctx c = cc;
   relaunder(c);
   const int ksteps = wpad(K) / 32;
@@ -751,8 +765,32 @@ __device__ __forceinline__ void fwd_heads(const Ctx& cc, int half, const Next& n
     const int r = c.wm * WROWS + rt * 16 + c.c16;
     am += *reinterpret_cast<const f32x4*>(bias + f0);            // features >= Z: zero weight rows, zero bias
     al += *reinterpret_cast<const f32x4*>(bias + Zs + f0);
-    *(GAS f32x4*)(mu_out + r * Zs + f0) = am;
-    *(GAS f32x4*)(lv_out + r * Zs + f0) = al;
+    if (zdst) {
+      const nm_job_t* J = c.job;
+      float ep[4];
+      if (J->eps) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ep[i] = asg(J->eps)[((int64_t)(step % J->eps_cap) * ROWS + r) * Z + min(f0 + i, Z - 1)];
+      } else if (pair_draw) {                                    // the generators of the fusion phase, same keys
+        randn2_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)(f0 >> 1), ep[0], ep[1]);
+        randn2_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)(f0 >> 1) + 1u, ep[2], ep[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ep[i] = randn_ctr(J->seed, (uint32_t)step, (uint32_t)(c.row0 + r), (uint32_t)(f0 + i));
+      }
+      bf16x4 zk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lv2 = logf(expf(al[i]));                     // variance and back, as the reference does
+        const float zz = am[i] + ep[i] * expf(0.5f * lv2);
+        zk[i] = (__bf16)((f0 + i < Z) ? zz : 0.f);
+        if (kl_out && r < c.nrows && f0 + i < Z) *kl_out += -0.5f * (1.0f + lv2 - am[i] * am[i] - expf(lv2));
+      }
+      *reinterpret_cast<bf16x4*>(zdst + r * 32 + f0) = zk;
+    } else {
+      *(GAS f32x4*)(mu_out + r * Zs + f0) = am;
+      *(GAS f32x4*)(lv_out + r * Zs + f0) = al;
+    }
   }
   lds_barrier();                          // P and the image are drained (the latent hand-off has its own barrier)
   tr(c, 2);
@@ -948,9 +986,13 @@ __device__ __forceinline__ int wgrad_adam(const Ctx& cc, const __bf16* A, int ld
   // request p / m / v of both tiles of unit u (wave-uniform) into set s: always WG_LOADS operations
   auto issue = [&](int u, PMV& s) {
     const int nt = u / nkp, kp = u - nt * nkp;            // wave-uniform: scalar division
-    const int t0 = min(kt0 + 2 * kp, KT - 1), t1 = min(kt0 + 2 * kp + 1, KT - 1);
-    const unsigned o0 = (unsigned)((T.w_off + ((int64_t)(nt * KT + t0) << 8)) << 2) + lane16;
-    const unsigned o1 = (unsigned)((T.w_off + ((int64_t)(nt * KT + t1) << 8)) << 2) + lane16;
+    // a tile outside the pass (the odd tile of the last pair, a bias-only column block) is requested anyway -- the count of
+    // operations must not depend on the unit -- from the first KiB of the buffers: every wave's filler hits the same hot
+    // lines (L1 / L2), so it costs no memory traffic; it is never stored
+    const int ktl0 = 2 * kp, ktl1 = 2 * kp + 1;
+    const bool v0 = ktl0 < nktp && kt0 + ktl0 < KT, v1 = ktl1 < nktp && kt0 + ktl1 < KT;
+    const unsigned o0 = (v0 ? (unsigned)((T.w_off + ((int64_t)(nt * KT + kt0 + ktl0) << 8)) << 2) : 0u) + lane16;
+    const unsigned o1 = (v1 ? (unsigned)((T.w_off + ((int64_t)(nt * KT + kt0 + ktl1) << 8)) << 2) : 0u) + lane16;
     NM_GLOAD16(s.p0, o0, Pp); NM_GLOAD16_NT(s.m0, o0, Mp); NM_GLOAD16_NT(s.v0, o0, Vp);
     NM_GLOAD16(s.p1, o1, Pp); NM_GLOAD16_NT(s.m1, o1, Mp); NM_GLOAD16_NT(s.v1, o1, Vp);
   };
@@ -1248,6 +1290,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // latent phases four columns at a time when the rows divide evenly (measured: with Z = 10 the 12-column groups
   // leave half the threads a second, mostly padded round -- slower than the element loop; Z = 64: 2.5x faster)
   const bool vec4 = S == 0 && (Z & 3) == 0;
+  // forward-only launch of a single-expert model (deviation pass, predictions from one modality): the latent draw is
+  // made inside the heads' epilogue (fwd_heads), see there
+  const bool fastlat = MODE == 3 && M == 1 && Me == 1 && J->single_bypass != 0 && !split && S == 0 && J->tc_weight == 0.f &&
+                       J->w_off < 0 && !(c.flags & NM_F_ZGIVEN) && wl.Zs <= 32 &&
+                       !((c.flags & NM_F_EXPORT) && (J->out_mu || J->out_logvar || J->out_z));
+  __bf16* const zlds = reinterpret_cast<__bf16*>(c.stage);      // [256][32] bf16 in S (free until the last decoder layer)
+  float kl_fast = 0.f;
   const bool sigm = J->out_kind == 1;           // sigmoid output, ll = -0.5 sum (x - x_hat)^2
   gf32 ws_mu_m = (gf32)(c.ws + wl.mu_m + (int64_t)(step & 1) * M * wl.lat);
   gf32 ws_lv_m = (gf32)(c.ws + wl.lv_m + (int64_t)(step & 1) * M * wl.lat);
@@ -1288,7 +1337,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     tr(c, 1);
     prof(c, PH_ENC_REST);
     fwd_heads(c, half, no_next(), Z, J->H[L - 1], ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs,
-              save ? ACT_STORES : 0);
+              save ? ACT_STORES : 0, fastlat ? zlds : (__bf16*)nullptr, step, vec4, &kl_fast);
     prof(c, PH_HEADS);
   }
 
@@ -1353,7 +1402,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   // Four latent columns of one row per iteration (16-byte loads of every expert's mu / logvar, 16-byte stores of the
   // joint statistics).  The element-at-a-time
   // loop spent its time waiting -- each iteration's loads queue behind the previous iteration's stores.
-  if (vec4) {
+  if (fastlat) {
+    kl_part = kl_fast;                             // (the draw and the KL terms were formed in the heads' epilogue)
+  } else if (vec4) {
     const int nq4 = (Z + 3) >> 2;
     const float rq4 = 1.0f / (float)nq4;
 #pragma unroll 2
@@ -1431,7 +1482,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   }
   }
   float kl = (MODE == 2) ? 0.f : block_sum(c, kl_part) * c.inv_b;          // calc_kl: sum over z, mean over rows
-  handoff_barrier();                                   // mu_j / es are complete for build_zc
+  if (fastlat) lds_barrier();                          // (z sits in LDS; the decoder image just requested stays in flight)
+  else handoff_barrier();                              // mu_j / es are complete for build_zc
   tr(c, 3);
   prof(c, PH_LATENT);
 
@@ -1458,7 +1510,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     } else {
     if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
     if (m == 0 || !reuse_zc) {
-      build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs, S, ws_mu_m + (int64_t)min(m, Me - 1) * ROWS * Zs);
+      build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs, S, ws_mu_m + (int64_t)min(m, Me - 1) * ROWS * Zs,
+               fastlat ? zlds : (const __bf16*)nullptr);
       lds_barrier();
       if (save || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P);
     } else {
@@ -2986,11 +3039,14 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 // Shadow images from the fp32 master: one workgroup per job.  A matrix is walked in master (tile) order; element
 // (n, k) goes to image row row0 + n, column k of `img` (row pitch `pitch` bytes), k-chunked every `kchunk` columns
 // with `kstride` bytes between chunk images, n-chunked every `nchunk` rows with `nstride` bytes between chunk blobs.
+// (the shadow rebuild runs as gridDim.y blocks per job that share the element loops)
+__device__ __forceinline__ int sh_tid() { return (int)(blockIdx.y * blockDim.x + threadIdx.x); }
+__device__ __forceinline__ int sh_nthr() { return (int)(blockDim.x * gridDim.y); }
 __device__ __forceinline__ void sync_matrix(const float* prm, int64_t w_off, int N, int K, char* img, int pitch, int kchunk,
                                             int64_t kstride, int nchunk, int64_t nstride) {
   const int KT = ktiles(K);
   const int64_t total = wt_elems(N, K);
-  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+  for (int64_t e = sh_tid(); e < total; e += sh_nthr()) {
     const int tile = (int)(e >> 8), r = (int)(e >> 4) & 15, cidx = (int)e & 15;
     const int n = (tile / KT) * 16 + r, k = (tile % KT) * 16 + cidx;
     const __bf16 h = (__bf16)prm[w_off + e];
@@ -3034,25 +3090,25 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
       const int nch = (md.Kx + XCH - 1) / XCH;
       sync_matrix(prm, md.enc_w[0], J->H[0], md.D + C, wsh + md.enc_s[0], LDX * 2, XCH, W0IMG_BYTES, BIG, 0);
       float* b0 = (float*)(wsh + md.enc_s[0] + (int64_t)nch * W0IMG_BYTES);
-      for (int i = threadIdx.x; i < J->H[0]; i += blockDim.x) b0[i] = prm[md.enc_b[0] + i];
+      for (int i = sh_tid(); i < J->H[0]; i += sh_nthr()) b0[i] = prm[md.enc_b[0] + i];
       for (int e = 1; e < L; ++e) {
         sync_matrix(prm, md.enc_w[e], J->H[e], J->H[e - 1], wsh + md.enc_s[e], LDP * 2, BIG, 0, BIG, 0);
         float* b = (float*)(wsh + md.enc_s[e] + IMG_BYTES);
-        for (int i = threadIdx.x; i < J->H[e]; i += blockDim.x) b[i] = prm[md.enc_b[e] + i];
+        for (int i = sh_tid(); i < J->H[e]; i += sh_nthr()) b[i] = prm[md.enc_b[e] + i];
       }
       sync_matrix(prm, md.mu_w, Z, J->H[L - 1], wsh + md.heads_s, LDP * 2, BIG, 0, BIG, 0);
       sync_matrix(prm, md.lv_w, Z, J->H[L - 1], wsh + md.heads_s + (int64_t)Zs * LDP * 2, LDP * 2, BIG, 0, BIG, 0);
       float* bh = (float*)(wsh + md.heads_s + IMG_BYTES);
-      for (int i = threadIdx.x; i < Z; i += blockDim.x) { bh[i] = prm[md.mu_b + i]; bh[Zs + i] = prm[md.lv_b + i]; }
+      for (int i = sh_tid(); i < Z; i += sh_nthr()) { bh[i] = prm[md.mu_b + i]; bh[Zs + i] = prm[md.lv_b + i]; }
     }
     for (int d = 0; d < L; ++d) {
       const int Kin = d == 0 ? Z + C : J->H[L - d], Nout = J->H[L - 1 - d];
       sync_matrix(prm, md.dec_w[d], Nout, Kin, wsh + md.dec_s[d], LDP * 2, BIG, 0, BIG, 0);
       float* b = (float*)(wsh + md.dec_s[d] + IMG_BYTES);
-      for (int i = threadIdx.x; i < Nout; i += blockDim.x) b[i] = prm[md.dec_b[d] + i];
+      for (int i = sh_tid(); i < Nout; i += sh_nthr()) b[i] = prm[md.dec_b[d] + i];
     }
     sync_matrix(prm, md.out_w, md.D, J->H[0], wsh + md.out_s, LDP * 2, BIG, 0, OCH, OBLOB_BYTES);
-    for (int i = threadIdx.x; i < md.D; i += blockDim.x) {
+    for (int i = sh_tid(); i < md.D; i += sh_nthr()) {
       float* vb = (float*)(wsh + md.out_s + (int64_t)(i / OCH) * OBLOB_BYTES + OIMG_BYTES);
       vb[i % OCH] = prm[md.out_b + i];
       if (J->out_kind == 0) vb[OCH + i % OCH] = prm[md.logvar_out + i];
@@ -3062,7 +3118,7 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
     const int nq = head_chunk0(J, Me);
     sync_matrix(prm, J->reg_w[0], 128, nq * XCH, wsh + J->reg_s, LDX * 2, XCH, W0IMG_BYTES, BIG, 0);
     float* b = (float*)(wsh + J->reg_s + (int64_t)nq * W0IMG_BYTES);
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) b[i] = prm[J->reg_b[0] + i];
+    for (int i = sh_tid(); i < 128; i += sh_nthr()) b[i] = prm[J->reg_b[0] + i];
   }
 }
 
@@ -3347,7 +3403,9 @@ int64_t nm_fill_shadow(nm_job_t* j) {
 int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1) return -8;
-  hipLaunchKernelGGL(sync_shadow_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  // few jobs (the eager facade: one): many blocks per job, so that the rebuild is not one workgroup's serial loop
+  const int slices = n_jobs >= 64 ? 4 : (n_jobs >= 8 ? 16 : 64);
+  hipLaunchKernelGGL(sync_shadow_kernel, dim3(n_jobs, slices), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return (int)hipGetLastError();
 }
 

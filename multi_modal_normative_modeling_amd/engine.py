@@ -75,6 +75,25 @@ class Table:
                                      self.x_pitch, self.cz.data_ptr(), self.Cz, _stream_ptr(dev)), "nm_pack_table")
         self.device = dev
 
+    def repack(self, x, c) -> bool:
+        """Overwrite this table's contents with a new batch of the same shape (the eager facade calls the model once per
+        batch: the buffers, and with them the job descriptor, stay as they are).  False if the shapes differ."""
+        if not (torch.is_tensor(x) and torch.is_tensor(c)) or x.dim() != 2 or c.dim() != 2:
+            return False
+        if int(x.shape[0]) != self.N or int(x.shape[1]) != self.D or int(c.shape[1]) != self.C or int(c.shape[0]) != self.N:
+            return False
+        lib = _lib.load()
+        dev = self.device
+        self.c_key = (("dev", c.data_ptr(), tuple(c.shape), str(c.dtype), c._version) if c.is_cuda else
+                      ("host", id(c), tuple(c.shape), str(c.dtype), c._version))
+        xs = x.to(device=dev, dtype=torch.float32).contiguous()
+        cs = c.to(device=dev, dtype=torch.float32).contiguous()
+        self._keep = (c, xs, cs)
+        _lib.check(lib.nm_pack_table(xs.data_ptr(), cs.data_ptr() if self.C > 0 else None, self.N, self.rows_alloc,
+                                     self.D, self.C, self.Kx, self.xb.data_ptr(), self.x_f32.data_ptr(),
+                                     self.x_pitch, self.cz.data_ptr(), self.Cz, _stream_ptr(dev)), "nm_pack_table")
+        return True
+
     def packed_rows(self) -> torch.Tensor:
         """The packed operand rows x | c | 1 | 0 as a [rows_alloc, Kx] tensor (diagnostics / tests)."""
         nch = (self.Kx + 63) // 64
@@ -310,6 +329,7 @@ class Job:
         j.dephase = int(self.dephase_sleeps)
         k0 = self.tables[0].c_key
         j.shared_cov = 1 if (k0 is not None and all(t.c_key == k0 for t in self.tables)) else 0
+        self._shared_cov = int(j.shared_cov)
         j.wide = int(s.wide)
         j.loss_cap, j.eps_cap = self.loss_cap, self.eps_cap
         j.lr, j.beta1, j.beta2, j.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
@@ -405,22 +425,38 @@ class JobSet:
         self._sig = None
         self._split_pending = False      # a split launch has run since the hand-off error words were last read
 
-    def check_split_errors(self):
-        """Raise NmError if a hand-off of a split launch (one workgroup per modality) timed out since the last check:
-        the job's workgroups left that launch, its parameters are not to be trusted.  Called before the next launch
-        of this set and by everything that reads results (assert_finite, losses, sweep.save_model); costs one small
-        kernel + a 4-byte-per-job copy, and only after a split launch."""
-        if not self._split_pending or self._dev is None:
-            return
-        out = torch.zeros(len(self.jobs), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.nm_split_errors(self._dev.data_ptr(), len(self.jobs), out.data_ptr(), 1,
-                                            _stream_ptr(self.device)), "nm_split_errors")
-        self._split_pending = False
-        bad = out.nonzero().flatten().tolist()
-        if bad:
-            raise _lib.NmError(f"split launch: the hand-off between the workgroups of job(s) {bad[:8]} timed out "
-                               f"(the parts of a model must all be resident at once: another stream or process "
-                               f"occupying CUs breaks that); their parameters are not valid -- re-run with NMHIP_SPLIT=0")
+    def check_split_errors(self, block: bool = True):
+        """Raise NmError if a hand-off of a split launch (one workgroup per modality) timed out: the job's workgroups left
+        that launch, its parameters are not to be trusted.  The error words are fetched asynchronously (a small kernel + a
+        copy into pinned memory behind the launch); block=True -- everything that reads results: assert_finite, losses,
+        sweep.save_model -- waits for the words of every split launch so far; block=False -- before the next launch of
+        this set -- only looks at words that have already arrived, so a loop of launches is never stalled by the check."""
+        infl = getattr(self, "_err_inflight", None)
+        if infl is not None:
+            ev, host = infl
+            if block:
+                ev.synchronize()
+            if ev.query():
+                self._err_inflight = None
+                bad = host.nonzero().flatten().tolist()
+                if bad:
+                    raise _lib.NmError(f"split launch: the hand-off between the workgroups of job(s) {bad[:8]} timed out "
+                                       f"(the parts of a model must all be resident at once: another stream or process "
+                                       f"occupying CUs breaks that); their parameters are not valid -- re-run with NMHIP_SPLIT=0")
+        if self._split_pending and self._dev is not None and getattr(self, "_err_inflight", None) is None:
+            n = len(self.jobs)
+            if getattr(self, "_err_dev", None) is None:
+                self._err_dev = torch.zeros(n, dtype=torch.int32, device=self.device)
+                self._err_host = torch.zeros(n, dtype=torch.int32).pin_memory()
+            _lib.check(self.lib.nm_split_errors(self._dev.data_ptr(), n, self._err_dev.data_ptr(), 1,
+                                                _stream_ptr(self.device)), "nm_split_errors")
+            self._err_host.copy_(self._err_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._err_inflight = (ev, self._err_host)
+            self._split_pending = False
+            if block:
+                self.check_split_errors(True)
 
     def _set_dephase(self):
         """Start offsets of the jobs of a long launch (nm_job_t.dephase): workgroup b lands on XCD b mod 8 (observed
@@ -452,7 +488,7 @@ class JobSet:
     def _upload(self, n_tiles: int = 1):
         """Descriptor array on the device; rebuilt only when a job's descriptor changed (the
         optimizer step count rides on adam_off = t - step, constant while both advance)."""
-        self.check_split_errors()
+        self.check_split_errors(block=False)
         self._set_dephase()
         for j in self.jobs:
             j._ensure_workspace(n_tiles)
@@ -476,6 +512,13 @@ class JobSet:
         fn = self.lib.nm_launch_wide if self.wide else (self.lib.nm_launch_scalar_tr if scalar_tr else self.lib.nm_launch)
         _lib.check(fn(ptr, len(self.jobs), int(step0), int(steps_per_tile), int(n_tiles), int(flags),
                       _stream_ptr(self.device)), "nm_launch_wide" if self.wide else "nm_launch")
+
+    def _launch_split(self, step0, n_steps, flags):
+        """nm_launch_split: every model as one workgroup per modality (small sets; see split_parts)."""
+        ptr = self._upload(1)
+        _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), len(self.jobs[0].kmods), int(step0), int(n_steps), int(flags),
+                                            _stream_ptr(self.device)), "nm_launch_split")
+        self._split_pending = True
 
     def split_parts(self) -> int:
         """Workgroups per model for a training launch: the M modalities of a model as separate workgroups when the

@@ -313,17 +313,27 @@ class ParamLayout:
             self._perm = nat.to(torch.int64)
         return self._perm if device is None else self._perm.to(device)
 
+    def _perm_pair(self, device):
+        """(positions in the natural buffer that hold an element, their positions in the kernel buffer), on `device`,
+        built once per device: both conversions below are then two index kernels, no mask, no host round trip."""
+        key = str(device)
+        cache = self.__dict__.setdefault("_perm_dev", {})
+        if key not in cache:
+            p = self.perm()
+            ok = (p >= 0).nonzero().flatten()
+            cache[key] = (ok.to(device), p[ok].to(device))
+        return cache[key]
+
     def nat_to_kernel(self, nat: torch.Tensor, out: torch.Tensor):
-        p = self.perm(nat.device)
-        ok = p >= 0
+        """natural buffer -> kernel buffer (16 x 16 tiles, zero padding)."""
+        i_nat, i_ker = self._perm_pair(nat.device)
         out.zero_()
-        out[p[ok]] = nat[ok]
+        out.index_copy_(0, i_ker, nat.index_select(0, i_nat))
         return out
 
     def kernel_to_nat(self, flat: torch.Tensor, out: torch.Tensor):
-        p = self.perm(flat.device)
-        ok = p >= 0
-        out[ok] = flat[p[ok]]
+        i_nat, i_ker = self._perm_pair(flat.device)
+        out.index_copy_(0, i_nat, flat.index_select(0, i_ker))
         return out
 
     def init_reference_rule(self, seed: int = 42) -> Dict[str, torch.Tensor]:

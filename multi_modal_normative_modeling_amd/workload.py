@@ -63,7 +63,13 @@ def build_sweep_jobs(cohort: prep.SyntheticCohort, procedure: str, n_folds: int,
     for j in range(n_jobs):
         # workgroups b and b + 8 share an XCD (and its L2): with xcd_affinity the models that read the same
         # fold tables are the ones that share an L2 (speed only; results do not depend on placement)
-        k = (j % 8) % n_folds if xcd_affinity else j % n_folds
+        if xcd_affinity == "rank":
+            # balanced variant: order the jobs by (XCD, slot) and cut that order into n_folds equal runs -- every fold
+            # keeps its n_jobs / n_folds models, every XCD hosts the models of at most two folds
+            per = (n_jobs + 7) // 8
+            k = min(((j % 8) * per + j // 8) * n_folds // max(n_jobs, 1), n_folds - 1)
+        else:
+            k = (j % 8) % n_folds if xcd_affinity else j % n_folds
         if k not in tables:
             xs, c = prep.fold_train_tables(cohort, mods, folds[k][0])
             tables[k] = [Table(x, c, device) for x in xs]

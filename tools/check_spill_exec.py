@@ -49,8 +49,6 @@ def resources(asm_text: str):
     out, cur = {}, None
     for l in asm_text.split("\n"):
         m = re.match(r"\s*\.name:\s+(\S+)", l)
-        if m and not l.strip().startswith(".name:           _ZN") and False:
-            pass
         if m:
             cur = m.group(1)
         m2 = re.match(r"\s*\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", l)
@@ -59,8 +57,17 @@ def resources(asm_text: str):
     return out
 
 
-# ceilings for the persistent step kernel: it must not spill vector registers or touch scratch in its loop
-STEP_KERNEL_LIMITS = {"vgpr_spill_count": 0, "private_segment_fixed_size": 0}
+# Ceilings per kernel family (substring of the mangled name).  The persistent kernels must not spill vector registers;
+# the step / general-shape kernels must not touch scratch at all.  SGPR spills (v_writelane / v_readlane into a reserved
+# VGPR, no memory traffic) are bounded at what the current source needs plus a margin, so that a change that makes the
+# scalar pressure worse is seen at build time (round 2 built 458 / 512 without anyone looking).
+LIMITS = {
+    "nm_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 520},
+    "nm_wide_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 300},
+    "nm_head_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 96, "sgpr_spill_count": 580},
+    "nm_reghead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 16},
+    "nm_clshead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 96, "sgpr_spill_count": 16},
+}
 
 
 def compile_isa() -> str:
@@ -84,11 +91,12 @@ def main():
         short = name.split("N_1")[-1][:34]
         print(f"  {short:36s} vgpr {r.get('vgpr_count', -1):3d}  vgpr spills {r.get('vgpr_spill_count', -1):3d}  "
               f"sgpr spills {r.get('sgpr_spill_count', -1):3d}  scratch {r.get('private_segment_fixed_size', -1):4d} B")
-        if "nm_step_kernel" in name:
-            for k, lim in STEP_KERNEL_LIMITS.items():
-                if r.get(k, 0) > lim:
-                    print(f"  !! {name}: {k} = {r[k]} exceeds the ceiling {lim}")
-                    rc = 1
+        for fam, limits in LIMITS.items():
+            if fam in name:
+                for k, lim in limits.items():
+                    if r.get(k, 0) > lim:
+                        print(f"  !! {name}: {k} = {r[k]} exceeds the ceiling {lim}")
+                        rc = 1
     return rc
 
 
