@@ -462,7 +462,12 @@ def build_parser():
                     help="one or more of SM-<modality> | SE-<combine> | UCA-<combine>")
     ap.add_argument("-E", "--epochs", dest="epochs", type=int, default=200)
     ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=10)
-    ap.add_argument("-O", "--oversample_percentage", dest="oversample_percentage", type=float, default=1.0)
+    ap.add_argument("-O", "--oversample_percentage", dest="oversample_percentage", type=float, default=1.0,
+                    help="any value but 1.0 (or -TrainingClass other than nm): the reference's fold recipe (utils.generate_kfold_ids, "
+                         "utils.py:73-93: KFold over healthy + other, bootstrap resample of the train split with replacement).  "
+                         "At the default 1.0 / nm this entry trains on the plain KFold split, every row once -- a deliberate "
+                         "deviation: the reference resamples with replacement even at 1.0.  Either way the fold's train / test "
+                         "IIDs are saved with the model (--save-models) and the `test` subcommand scores exactly the held-out rows")
     ap.add_argument("-Model", "--model", dest="model", type=str, default="cVAE_multimodal")
     ap.add_argument("-SingleModality", "--single_modality", dest="single_modality", type=str, default=None)
     ap.add_argument("-Baselearningrate", "--base_learning_rate", dest="base_learning_rate", type=float, default=1e-4)

@@ -1142,3 +1142,68 @@ def test_reference_loop_and_sweep_cli_on_wide_shapes():
         assert table.shape[0] == 4 and torch.isfinite(table[:, 3]).all()
         df = pd.read_csv(f"{d}/HCPimage/SE-gPoE/deviation_fold_0_fMRI_roiwise.csv")
         assert df.shape == (300, 380) and np.isfinite(df.to_numpy()[:, 1:]).all()
+
+
+@pytest.mark.parametrize("model,oversample", [("DMVAE", "1.0"), ("mmJSD", "1.0"), ("cVAE_multimodal", "1.5")])
+def test_train_then_test_for_zoo_models_and_resampled_folds(model, oversample):
+    """train --save-models -> test for the model classes whose tables / fusion differ from the default: the DMVAE
+    family takes no covariates (its test tables are packed without the covariate block), mmJSD always reconstructs with
+    the plain product of experts whatever the procedure says; and with -O != 1 the train entry splits the folds with the
+    reference's bootstrap recipe -- the `test` subcommand must then score the rows saved with the model, not a KFold of its
+    own (no subject of a fold's test file is among the fold's train ids)."""
+    with tempfile.TemporaryDirectory() as d:
+        sweep.main(["-P", "SE-gPoE", "-E", "2", "-K", "2", "--subjects", "300", "--out-dir", d, "--save-models", "--no-csv",
+                    "-Model", model, "-O", oversample])
+        base = f"{d}/HCPimage/SE-gPoE"
+        ck = torch.load(f"{base}/000/cVAE_model_state.pt", weights_only=True)
+        assert ck["model"] == model and ck["combine"] == ("gpoe" if model == "cVAE_multimodal" else "poe")
+        errs = sweep.main_test(["-P", "SE-gPoE", "-K", "2", "--subjects", "300", "--models-dir", d])
+        assert set(errs) == set(prep.HCP_MODALITIES) and all(np.isfinite(v).all() and len(v) > 0 for v in errs.values())
+        for k in (0, 1):
+            tr = set(pd.read_csv(f"{base}/{k:03d}/train_ids.csv")["IID"].tolist())
+            te = pd.read_csv(f"{base}/{k:03d}/test_ids.csv")["IID"].tolist()
+            scored = pd.read_csv(f"{base}/{k:03d}/fMRI/reconstruction_error_fMRI.csv")["participant_id"].tolist()
+            assert sorted(scored) == sorted(te) and not (set(scored) & tr)
+
+
+def test_facade_buffer_reuse_is_stateless():
+    """The drop-in class keeps one job, its tables and the draw buffer from call to call (Table.repack).  Whatever the
+    sequence of calls -- full batch, ragged tail, back to full, CPU tensors, per-modality covariates after shared ones,
+    another combiner -- every call must return what a freshly built model with the same weights returns."""
+    g = Golden("mm3_gpoe")
+    torch.manual_seed(1)
+    gen = torch.Generator().manual_seed(8)
+    dims, Z, cdim = g.dims, g.Z, g.c_dim
+
+    def batch(B, shared_c=True):
+        xs = [torch.randn(B, d, generator=gen) for d in dims]
+        c0 = (torch.rand(B, cdim, generator=gen) < 0.2).float()
+        cs = [c0] * 3 if shared_c else [c0, 1 - c0, c0 * 0.5]
+        return xs, cs, torch.randn(B, Z, generator=gen)
+
+    def fresh(sd):
+        m = nm.cVAE_multimodal(dims, g.hidden, Z, cdim, modalities=3, non_linear=True)
+        m.load_state_dict(sd)
+        return m.to(DEV)
+
+    model = fresh(g.weights("w0"))
+    plan = [(256, True, "gpoe", True), (83, True, "gpoe", True), (256, True, "gpoe", False), (256, False, "gpoe", True),
+            (256, True, "moe", True), (40, False, "poe", False), (256, True, "gpoe", True)]
+    for B, shared, comb, on_dev in plan:
+        xs, cs, eps = batch(B, shared)
+        put = (lambda t: t.to(DEV)) if on_dev else (lambda t: t)
+        sd = model.state_dict()
+        ref = fresh(sd)
+        outs = []
+        for m in (model, ref):
+            m._eps_override = eps
+            fwd = m.forward_multimodal([put(x) for x in xs], [put(c) for c in cs], comb)
+            loss = m.loss_function_multimodal(xs, fwd)
+            m.optimizer1.zero_grad(); loss["total"].backward()
+            grads = {n: q.grad.detach().cpu().clone() for n, q in m.named_parameters() if q.grad is not None}
+            outs.append((float(loss["total"]), float(loss["ll"]), fwd["x_recons"][1].loc.cpu(), grads))
+        model.optimizer1.step()                            # (the long-lived model moves on; its Adam clock differs from a fresh one)
+        a, b = outs
+        assert a[0] == b[0] and a[1] == b[1], (B, shared, comb, a[:2], b[:2])
+        assert torch.equal(a[2], b[2])
+        assert a[3].keys() == b[3].keys() and all(torch.equal(a[3][k], b[3][k]) for k in a[3]), (B, shared, comb)
