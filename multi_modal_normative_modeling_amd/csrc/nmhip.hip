@@ -451,23 +451,48 @@ __device__ __forceinline__ bool split_handoff(const Ctx& c, GAS unsigned* cnt, G
   return *c.abort == 0u;
 }
 
-// What a GEMM phase requests for the phase after it: `np` 1-KiB pieces src -> dst and, optionally, one more piece
-// (the fp32 vectors that travel with a weight image) vsrc -> vdst.
+// Hidden / heads / decoder weight blobs in memory: the matrix COMPACT, [rows][kp] bf16 row-major with kp = blob_kp(K) (the
+// ones column and the 16-column tiles of the Adam stores included), then -- 1-KiB aligned -- the fp32 vector piece.
+// global_load_lds takes a per-lane source address, so the copy into LDS still lands as the [128][136] image the GEMMs
+// read: segments outside the matrix (pad rows / pad columns) come from one line of zeros at the start of job.wsh.
+// (round 2 stored the padded image itself: 34.8 KB read twice per step for a 110 x 111 layer, 7-25 KB now)
+__host__ __device__ inline int blob_kp(int K) { const int a = rup(K + 1, 8), b = rup(K, 16); return a > b ? a : b; }
+// (rows rounded to 16 in memory: the Adam units store whole 16-row tiles, pad rows stay zero)
+__host__ __device__ inline int cimg_bytes(int rows, int K) { return rup(rup(rows, 16) * blob_kp(K) * 2, 1024); }
+__host__ __device__ inline int cblob_bytes(int rows, int K) { return cimg_bytes(rows, K) + VEC_BYTES; }
+constexpr int WSH_ZERO_BYTES = 1024;     // job.wsh starts with zeros (never written): the source of every pad segment
+__device__ __forceinline__ int dma_img(const Ctx& c, const GAS char* src, char* dst, int rows, int kp, const GAS char* zero) {
+  int n = 0;
+  const int segs = kp >> 3;
+  for (int p = c.wave; p < (IMG_BYTES >> 10); p += NWAVES) {
+    const int q = (p << 6) + c.lane;                       // 16-byte segment of the LDS image
+    const int r = idiv(q, LDP / 8, 8.0f / (float)LDP), sg = q - (LDP / 8) * r;
+    const GAS char* a = (r < rows && sg < segs) ? src + (((int64_t)r * kp + sg * 8) << 1) : zero;
+    dma16<0>(a, dst + (p << 10));
+    ++n;
+  }
+  return n;
+}
+// What a GEMM phase requests for the phase after it: `np` 1-KiB pieces src -> dst (linear copy; rows > 0: a compact weight
+// matrix [rows][kp] into a [128][136] image, dma_img) and, optionally, one more piece (the fp32 vectors that travel with a
+// weight image) vsrc -> vdst.
 struct Next {
   const GAS char* src; char* dst; int np;
   const GAS char* vsrc; char* vdst;
+  int rows, kp;
 };
-__device__ __forceinline__ Next no_next() { return Next{nullptr, nullptr, 0, nullptr, nullptr}; }
+__device__ __forceinline__ Next no_next() { return Next{nullptr, nullptr, 0, nullptr, nullptr, 0, 0}; }
 __device__ __forceinline__ int issue_next(const Ctx& c, const Next& nx) {
   int n = 0;
-  if (nx.src) n = dma_lin(c, nx.src, nx.dst, nx.np);
+  if (nx.src) n = nx.rows > 0 ? dma_img(c, nx.src, nx.dst, nx.rows, nx.kp, (const GAS char*)c.job->wsh)
+                              : dma_lin(c, nx.src, nx.dst, nx.np);
   if (nx.vsrc && c.wave == 2) { dma16<0>(nx.vsrc + (c.lane << 4), nx.vdst); ++n; }
   return n;
 }
-// a [128][136] weight image + its vector piece into half `half` of Q / vector slot `half`
-__device__ __forceinline__ Next blob_to_half(const Ctx& c, const GAS char* blob, int half) {
-  return Next{blob, reinterpret_cast<char*>(c.Q) + half * IMG_BYTES, IMG_BYTES >> 10, blob + IMG_BYTES,
-              reinterpret_cast<char*>(c.vec) + half * VEC_BYTES};
+// the weight blob of a layer with `rows` output rows and K inputs (+ its vector piece) into half `half` of Q / vector slot `half`
+__device__ __forceinline__ Next blob_to_half(const Ctx& c, const GAS char* blob, int half, int rows, int K) {
+  return Next{blob, reinterpret_cast<char*>(c.Q) + half * IMG_BYTES, IMG_BYTES >> 10, blob + cimg_bytes(rows, K),
+              reinterpret_cast<char*>(c.vec) + half * VEC_BYTES, rows, blob_kp(K)};
 }
 
 // ---- cooperative copies ----------------------------------------------------------------------
@@ -850,11 +875,11 @@ __device__ __forceinline__ void dgrad_tile(const Ctx& c, f32x4 (&acc)[2][RT], co
 // the dgrad the lower 128 rows follow (still in flight on return: the caller's wgrad_adam(..., pending = 0) waits), so that
 // Q = input activation for wgrad and the ReLU mask.
 __device__ __forceinline__ void dgrad_hidden(const Ctx& cc, f32x4 (&acc)[2][RT], const GAS char* w_img, const GAS char* act_img,
-                                             int N) {
+                                             int N, int K) {
   Ctx c = cc;
   relaunder(c);
   char* Qb = reinterpret_cast<char*>(c.Q);
-  dma_lin(c, w_img, Qb, IMG_BYTES >> 10);
+  dma_img(c, w_img, Qb, N, blob_kp(K), (const GAS char*)c.job->wsh);
   const int n_hi = dma_lin(c, act_img + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
   wait_vm(n_hi);
   lds_barrier();
@@ -1323,15 +1348,17 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     const nm_modality_t& md = J->mod[m];
     gbf16 save0 = save ? (gbf16)(ws_enc + (int64_t)(m * L + 0) * ACT_BYTES) : (gbf16)nullptr;
     // the image of the phase after the first layer goes to the lower half of Q
+    // (rows / inputs of that blob: the second encoder layer, or the heads' [mu | logvar] rows)
     const GAS char* after0 = wsh + (L > 1 ? md.enc_s[1] : md.heads_s);
     fwd_first_layer(c, (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * ((md.Kx + XCH - 1) / XCH) * XIMG_BYTES, md.Kx,
-                    wsh + md.enc_s[0], blob_to_half(c, after0, 0), J->H[0], nl, save0);
+                    wsh + md.enc_s[0], blob_to_half(c, after0, 0, L > 1 ? J->H[1] : 2 * Zs, J->H[0]), J->H[0], nl, save0);
     prof(c, PH_ENC_L0);
     int half = 0;
     for (int e = 1; e < L; ++e) {
       gbf16 sv = save ? (gbf16)(ws_enc + (int64_t)(m * L + e) * ACT_BYTES) : (gbf16)nullptr;
       const GAS char* nxt = wsh + (e + 1 < L ? md.enc_s[e + 1] : md.heads_s);
-      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1), J->H[e], J->H[e - 1], nl, sv, save ? ACT_STORES : 0);
+      fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1, e + 1 < L ? J->H[e + 1] : 2 * Zs, J->H[e]), J->H[e], J->H[e - 1], nl, sv,
+                save ? ACT_STORES : 0);
       half ^= 1;
     }
     tr(c, 1);
@@ -1346,7 +1373,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
   if (split) { if (!split_handoff(c, sync_a, sync_err, sync_target)) return; }
   else handoff_barrier();
   // first decoder layer's image: requested now, lands during the latent arithmetic
-  if (MODE != 2) issue_next(c, blob_to_half(c, wsh + J->mod[split ? part : 0].dec_s[0], 0));
+  if (MODE != 2) issue_next(c, blob_to_half(c, wsh + J->mod[split ? part : 0].dec_s[0], 0, J->H[L - 1], Z + C));
   float al[NM_MAX_EXP] = {0.f, 0.f, 0.f, 0.f};
   if (J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass)) softmax_alpha(J, al);
   auto load_lat = [&](Lat& Lt, int r, int z) {
@@ -1508,7 +1535,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       dma_lin(c, ws_dec + (int64_t)(L - 1) * ACT_BYTES, Pb, ACT_BYTES >> 10);
       dma_lin(c, oblob, Sb, OBLOB_BYTES >> 10);
     } else {
-    if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0));
+    if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0, J->H[L - 1], Z + C));
     if (m == 0 || !reuse_zc) {
       build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs, S, ws_mu_m + (int64_t)min(m, Me - 1) * ROWS * Zs,
                fastlat ? zlds : (const __bf16*)nullptr);
@@ -1525,8 +1552,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       int Kin = (d == 0) ? Kd0 : J->H[L - d];
       int Nout = J->H[L - 1 - d];
       gbf16 sv = (save && (d < L - 1 || MODE == 1)) ? (gbf16)(ws_dec + (int64_t)d * ACT_BYTES) : (gbf16)nullptr;
-      Next nx = (d + 1 < L) ? blob_to_half(c, wsh + md.dec_s[d + 1], half ^ 1)
-                            : Next{oblob, Sb, OBLOB_BYTES >> 10, nullptr, nullptr};
+      Next nx = (d + 1 < L) ? blob_to_half(c, wsh + md.dec_s[d + 1], half ^ 1, J->H[L - 2 - d], Nout)
+                            : Next{oblob, Sb, OBLOB_BYTES >> 10, nullptr, nullptr, 0, 0};
       // (d == 0: the z | c | 1 build / reload sits between the image request and here -- wait for everything)
       fwd_layer(c, half, nx, Nout, Kin, nl, sv, (d > 0 && save) ? ACT_STORES : 0);
       half ^= 1;
@@ -1848,8 +1875,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       zero_acc(acc);
       const GAS char* act_img = d == 0 ? ws_zc : ws_dec + (int64_t)(d - 1) * ACT_BYTES;
       GAS char* const dimg = wsh + md.dec_s[d];
-      const WgGeom Gd{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.dec_w[d], md.dec_b[d], dimg, LDP * 2, (GAS float*)(dimg + IMG_BYTES), spatch}};
-      dgrad_hidden(c, acc, dimg, act_img, Nout);
+      const WgGeom Gd{Nout, Kin, 0, rup(Kin + 1, 16),
+                      WgT{md.dec_w[d], md.dec_b[d], dimg, blob_kp(Kin) * 2, (GAS float*)(dimg + cimg_bytes(Nout, Kin)), spatch}};
+      dgrad_hidden(c, acc, dimg, act_img, Nout, Kin);
       tr(c, 10);
       prof(c, PH_DEC_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gd, 0);
@@ -2078,7 +2106,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     // heads image -> lower half of Q, upper rows of the last hidden activation -> upper half: in flight while
     // P <- [d mu_m | 0 | d logvar_m | 0] is put together
     const GAS char* act_last = ws_enc + (int64_t)(m * L + (L - 1)) * ACT_BYTES;
-    dma_lin(c, wsh + md.heads_s, Qb, IMG_BYTES >> 10);
+    dma_img(c, wsh + md.heads_s, Qb, 2 * Zs, blob_kp(Hh), (const GAS char*)J->wsh);
     dma_lin(c, act_last + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
     if (once || once_ws) {                         // this expert's columns of the saved fusion backward
       const int segs = (2 * Zs) >> 3;              // 16-byte pieces per row
@@ -2193,10 +2221,12 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     tr(c, 13);
     {
       GAS char* img = wsh + md.heads_s;
-      const WgGeom Gm{Z, Hh, 0, rup(Hh + 1, 16), WgT{md.mu_w, md.mu_b, img, LDP * 2, (GAS float*)(img + IMG_BYTES), spatch}};
+      const int hkp = blob_kp(Hh);
+      GAS float* const hvec = (GAS float*)(img + cimg_bytes(2 * Zs, Hh));
+      const WgGeom Gm{Z, Hh, 0, rup(Hh + 1, 16), WgT{md.mu_w, md.mu_b, img, hkp * 2, hvec, spatch}};
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Gm, 0);
       const WgGeom Gl{Z, Hh, 0, rup(Hh + 1, 16),
-                      WgT{md.lv_w, md.lv_b, img + (int64_t)Zs * LDP * 2, LDP * 2, (GAS float*)(img + IMG_BYTES) + Zs, spatch}};
+                      WgT{md.lv_w, md.lv_b, img + (int64_t)Zs * hkp * 2, hkp * 2, hvec + Zs, spatch}};
       // (pending = 0: its barrier also separates this pass's bias hand-off through LDS from the previous pass's)
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, Zs, c.Q, LDP, Gl, 0);
     }
@@ -2208,8 +2238,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       int Kin = J->H[e - 1], Nout = J->H[e];
       zero_acc(acc);
       GAS char* const eimg = wsh + md.enc_s[e];
-      const WgGeom Ge{Nout, Kin, 0, rup(Kin + 1, 16), WgT{md.enc_w[e], md.enc_b[e], eimg, LDP * 2, (GAS float*)(eimg + IMG_BYTES), spatch}};
-      dgrad_hidden(c, acc, eimg, ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout);
+      const WgGeom Ge{Nout, Kin, 0, rup(Kin + 1, 16),
+                      WgT{md.enc_w[e], md.enc_b[e], eimg, blob_kp(Kin) * 2, (GAS float*)(eimg + cimg_bytes(Nout, Kin)), spatch}};
+      dgrad_hidden(c, acc, eimg, ws_enc + (int64_t)(m * L + (e - 1)) * ACT_BYTES, Nout, Kin);
       prof(c, PH_ENCB_DGRAD);
       wgrad_adam<SCALAR_TR>(c, c.P, LDP, 0, c.Q, LDP, Ge, 0);
       prof(c, PH_ENCB_WGRAD);
@@ -2344,6 +2375,11 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
 }
 
 #include "nm_wide.inc"
+
+// bytes of the trunk's part of a tile's workspace (the heads' own region sits behind it)
+__host__ __device__ inline int64_t trunk_ws_bytes(const nm_job_t* J) {
+  return J->wide ? wide_ws_layout(J).total : ws_layout(J->M, J->L, J->Z).total;
+}
 
 // ---- regression head (cVAE.py:2249-2253 regressor, 2318-2321 forward, 2330-2346 loss) ----------------
 // fi_pred = W3 relu(W2 relu(W1 cat_m(x_m - x_hat_m) + b1) + b2) + b3;  loss = mean_r (fi_pred - FI)^2.
@@ -2565,7 +2601,7 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
   const nm_job_t* J = jobs + blockIdx.x;
   Ctx c;
   if (!head_setup(c, smem, J, step, tile0, flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return;
-  reg_head_body(c, J, step, c.ws + ws_layout(J->M, J->L, J->Z).total, blockIdx.y == 0);
+  reg_head_body(c, J, step, c.ws + trunk_ws_bytes(J), blockIdx.y == 0);
 }
 
 // ---- classifier head of the end-to-end model (cVAE.py:2004-2018 Classifier, 2117 logits, 2140-2200 loss) ---
@@ -2962,7 +2998,7 @@ __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restri
   const nm_job_t* J = jobs + blockIdx.x;
   Ctx c;
   if (!head_setup(c, smem, J, step, tile0, flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return;
-  cls_head_body(c, J, step, c.ws + ws_layout(J->M, J->L, J->Z).total, blockIdx.y == 0, (flags & NM_F_BNSTATS) != 0);
+  cls_head_body(c, J, step, c.ws + trunk_ws_bytes(J), blockIdx.y == 0, (flags & NM_F_BNSTATS) != 0);
 }
 
 // ---- head models in one persistent launch ------------------------------------------------------------------------
@@ -2987,7 +3023,7 @@ __global__ __launch_bounds__(WG) void nm_head_step_kernel(const nm_job_t* __rest
   c.ws = (GAS char*)J->workspace;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
-  GAS char* const hws = c.ws + ws_layout(J->M, J->L, J->Z).total;
+  GAS char* const hws = c.ws + trunk_ws_bytes(J);
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
   const int tflags = flags & (NM_F_PROFILE | NM_F_TRACE);
   // NM_F_GRADS: gradients of the step's total into job.grads, no update (the eager facade's backward)
@@ -3092,19 +3128,20 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
       float* b0 = (float*)(wsh + md.enc_s[0] + (int64_t)nch * W0IMG_BYTES);
       for (int i = sh_tid(); i < J->H[0]; i += sh_nthr()) b0[i] = prm[md.enc_b[0] + i];
       for (int e = 1; e < L; ++e) {
-        sync_matrix(prm, md.enc_w[e], J->H[e], J->H[e - 1], wsh + md.enc_s[e], LDP * 2, BIG, 0, BIG, 0);
-        float* b = (float*)(wsh + md.enc_s[e] + IMG_BYTES);
+        sync_matrix(prm, md.enc_w[e], J->H[e], J->H[e - 1], wsh + md.enc_s[e], blob_kp(J->H[e - 1]) * 2, BIG, 0, BIG, 0);
+        float* b = (float*)(wsh + md.enc_s[e] + cimg_bytes(J->H[e], J->H[e - 1]));
         for (int i = sh_tid(); i < J->H[e]; i += sh_nthr()) b[i] = prm[md.enc_b[e] + i];
       }
-      sync_matrix(prm, md.mu_w, Z, J->H[L - 1], wsh + md.heads_s, LDP * 2, BIG, 0, BIG, 0);
-      sync_matrix(prm, md.lv_w, Z, J->H[L - 1], wsh + md.heads_s + (int64_t)Zs * LDP * 2, LDP * 2, BIG, 0, BIG, 0);
-      float* bh = (float*)(wsh + md.heads_s + IMG_BYTES);
+      const int hkp = blob_kp(J->H[L - 1]);
+      sync_matrix(prm, md.mu_w, Z, J->H[L - 1], wsh + md.heads_s, hkp * 2, BIG, 0, BIG, 0);
+      sync_matrix(prm, md.lv_w, Z, J->H[L - 1], wsh + md.heads_s + (int64_t)Zs * hkp * 2, hkp * 2, BIG, 0, BIG, 0);
+      float* bh = (float*)(wsh + md.heads_s + cimg_bytes(2 * Zs, J->H[L - 1]));
       for (int i = sh_tid(); i < Z; i += sh_nthr()) { bh[i] = prm[md.mu_b + i]; bh[Zs + i] = prm[md.lv_b + i]; }
     }
     for (int d = 0; d < L; ++d) {
       const int Kin = d == 0 ? Z + C : J->H[L - d], Nout = J->H[L - 1 - d];
-      sync_matrix(prm, md.dec_w[d], Nout, Kin, wsh + md.dec_s[d], LDP * 2, BIG, 0, BIG, 0);
-      float* b = (float*)(wsh + md.dec_s[d] + IMG_BYTES);
+      sync_matrix(prm, md.dec_w[d], Nout, Kin, wsh + md.dec_s[d], blob_kp(Kin) * 2, BIG, 0, BIG, 0);
+      float* b = (float*)(wsh + md.dec_s[d] + cimg_bytes(Nout, Kin));
       for (int i = sh_tid(); i < Nout; i += sh_nthr()) b[i] = prm[md.dec_b[d] + i];
     }
     sync_matrix(prm, md.out_w, md.D, J->H[0], wsh + md.out_s, LDP * 2, BIG, 0, OCH, OBLOB_BYTES);
@@ -3307,7 +3344,7 @@ const char* nm_status_string(int status) {
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
     case -18: return "out_kind must be 0 or 1, 0 <= n_private <= Z, and a private latent needs an encoder per decoder";
-    case -19: return "general-shape path (wide): plain cVAE / cVAE_multimodal models only (no heads, no DMVAE-family or mvtCAE switches)";
+    case -19: return "general-shape path (wide): cVAE / cVAE_multimodal / end-to-end trunk only (no regression head, no DMVAE-family or mvtCAE switches)";
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
@@ -3331,8 +3368,9 @@ int nm_validate_job(const nm_job_t* j) {
     for (int i = 0; i < j->L; ++i)
       if (j->H[i] < 1 || j->H[i] > NM_WIDE_MAX_WIDTH) return -4;
     if (j->Z < 1 || j->Z > NM_WIDE_MAX_LATENT) return -5;
-    if (j->out_kind != 0 || j->n_private != 0 || j->tc_weight != 0.f || j->w_off >= 0 || j->reg_head || j->cls_classes > 0 ||
-        (j->M_enc != 0 && j->M_enc != j->M) || j->combine == NM_COMBINE_POE2V)
+    // (the classifier head of the end-to-end model runs as its own kernel, nm_head_classifier, on any trunk)
+    if (j->out_kind != 0 || j->n_private != 0 || j->tc_weight != 0.f || j->w_off >= 0 || j->reg_head ||
+        j->combine == NM_COMBINE_POE2V)
       return -19;
   } else {
   for (int i = 0; i < j->L; ++i)
@@ -3380,7 +3418,8 @@ int64_t nm_fill_shadow(nm_job_t* j) {
   if (!j) return -1;
   if (j->M < 1 || j->M > NM_MAX_MOD || j->L < 1 || j->L > NM_MAX_HID) return -2;
   const int Me = j->M_enc > 0 ? j->M_enc : j->M;
-  int64_t o = 0;
+  const int Zs = rup(j->Z, 16), L = j->L;
+  int64_t o = WSH_ZERO_BYTES;                      // a line of zeros first: the source of every pad segment (dma_img)
   for (int m = 0; m < j->M; ++m) {
     nm_modality_t& md = j->mod[m];
     if (md.Kx < 32 || md.D < 1) return -7;
@@ -3389,10 +3428,13 @@ int64_t nm_fill_shadow(nm_job_t* j) {
     if (m < Me) {
       const int nch = (md.Kx + XCH - 1) / XCH;
       md.enc_s[0] = o; o += (int64_t)nch * W0IMG_BYTES + VEC_BYTES;
-      for (int e = 1; e < j->L; ++e) { md.enc_s[e] = o; o += BLOB_BYTES; }
-      md.heads_s = o; o += BLOB_BYTES;
+      for (int e = 1; e < L; ++e) { md.enc_s[e] = o; o += cblob_bytes(j->H[e], j->H[e - 1]); }
+      md.heads_s = o; o += cblob_bytes(2 * Zs, j->H[L - 1]);
     }
-    for (int d = 0; d < j->L; ++d) { md.dec_s[d] = o; o += BLOB_BYTES; }
+    for (int d = 0; d < L; ++d) {
+      md.dec_s[d] = o;
+      o += cblob_bytes(j->H[L - 1 - d], d == 0 ? j->Z + j->C : j->H[L - d]);
+    }
     md.out_s = o; o += (int64_t)((md.D + OCH - 1) / OCH) * OBLOB_BYTES;
   }
   j->reg_s = 0;
@@ -3411,8 +3453,7 @@ int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
 
 int64_t nm_workspace_bytes(const nm_job_t* j) {
   if (!j) return -1;
-  if (j->wide) return wide_ws_layout(j).total;
-  int64_t b = ws_layout(j->M, j->L, j->Z).total;      // the head's region sits behind the trunk's
+  int64_t b = trunk_ws_bytes(j);                      // the head's region sits behind the trunk's
   int64_t hb = 0;
   if (j->reg_head) hb = ACT_BYTES;        // regression head: its first hidden activation, kept for the backward pass
   if (j->cls_layers > 0 || j->cls_classes > 0) hb = hb > cls_ws_bytes() ? hb : cls_ws_bytes();

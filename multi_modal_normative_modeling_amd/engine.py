@@ -617,7 +617,7 @@ class JobSet:
         nb = self.jobs[0].batches_per_epoch
         if any(j.batches_per_epoch != nb for j in self.jobs):
             raise ValueError("jobs of one set must have the same number of batches")
-        if fused:
+        if fused and not self.wide:
             self._train_head(step0, n_steps, _lib.NM_F_BNSTATS)
         else:
             for s in range(step0, step0 + n_steps):

@@ -210,6 +210,11 @@ def test_regression_and_endtoend_command_lines_one_gpu():
         res = sweep.main_endtoend(["-E", "2", "-K", "5", "--folds", "1", "--subjects", "320", "-Dropout", "0.2", "--out-dir", d])
         assert len(res) == 1 and res[0]["fold"] == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
         assert pd.read_csv(f"{d}/HCPimage/endtoend_metrics_rank0.csv").shape[0] == 1
+        # an -H list of the end-to-end grid beyond the fused tile (commands_list9_endtoend.sh:24) and one of its -Layers lists
+        res = sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-H", "300", "300", "30", "-Layers", "128", "64"])
+        assert len(res) == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
+        with pytest.raises(ValueError):                          # a classifier deeper than the head kernel takes
+            sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "128", "64", "32", "16"])
 
 
 def test_train_then_test_command_lines():
@@ -452,7 +457,8 @@ def test_fused_endtoend_training_matches_reference_trajectory():
             assert float((sd[k] - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, k
 
 
-@pytest.mark.parametrize("dims,hidden,cdim,B", [([60, 45, 70], [40, 32], 5, 200), ([379, 379, 379], [110, 110], 29, 256)])
+@pytest.mark.parametrize("dims,hidden,cdim,B", [([60, 45, 70], [40, 32], 5, 200), ([379, 379, 379], [110, 110], 29, 256),
+                                                 ([60, 45, 70], [300, 160], 5, 200)])      # "-H 300 300 ..": the trunk on the general-shape path
 def test_classifier_head_config5_shape_vs_oracle(dims, hidden, cdim, B):
     """The end-to-end model with the config-5 head (Z = 64, classifier [128, 64, 32]) at a small trunk with a ragged batch
     of 200 and at BASELINE config 5's full shape (3 x 379 ROI, H = [110, 110], c = 29, batch 256): logits, cross entropy,
@@ -1207,3 +1213,47 @@ def test_facade_buffer_reuse_is_stateless():
         assert a[0] == b[0] and a[1] == b[1], (B, shared, comb, a[:2], b[:2])
         assert torch.equal(a[2], b[2])
         assert a[3].keys() == b[3].keys() and all(torch.equal(a[3][k], b[3][k]) for k in a[3]), (B, shared, comb)
+
+
+def test_endtoend_training_on_a_wide_trunk_matches_oracle_trajectory():
+    """cVAE_multimodal_endtoend with hidden widths beyond the fused tile (an -H list of commands_list9_endtoend.sh:24): the trunk
+    runs on the general-shape path, the classifier head in its own kernel, three launches per step (JobSet.train_endtoend);
+    two Adam steps against the oracle's trajectory (dropout 0)."""
+    dims, hidden, Z, cdim, B, layers = [50, 40, 45], [200, 144], 16, 7, 128, (32, 16)
+    spec = nm.ModelSpec(dims, hidden, Z, cdim, True, "endtoend", layers, 2)
+    assert spec.wide
+    P = nm.ParamLayout(spec).init_reference_rule(9)
+    g = torch.Generator().manual_seed(19)
+    xs = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.rand(B, cdim, generator=g)
+    labels = (torch.rand(B, generator=g) < 0.4).long()
+    eps = torch.randn(2, 256, Z, generator=g)
+    lr = 1e-3
+    job = nm.Job(spec, [nm.Table(x, c, DEV) for x in xs], combine="poe", state=P, lr=lr, kl_weight=0.1, ll_weight=0.1,
+                 single_bypass=False, loss_cap=4)
+    job.cls_dropout, job.cls_margin, job.cls_w_contrast = 0.0, 1.0, 0.1
+    job.set_labels(labels.int())
+    job.set_eps(eps)
+    js = nm.JobSet([job])
+    js.train_endtoend(2)
+    torch.cuda.synchronize()
+    js.assert_finite()
+    rs = R.Spec(dims, hidden, Z, cdim, True, kind="endtoend", classifier_layers=list(layers))
+    Pr = {k: v.clone() for k, v in P.items()}
+    names = [k for k in R.param_names(rs) if "running" not in k and "num_batches" not in k]
+    opt = R.Adam(Pr, names, lr=lr)
+    R.set_operand_rounding("bf16")
+    try:
+        for s in range(2):
+            leaves = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in Pr.items()}
+            of = R.forward_endtoend(leaves, rs, xs, [c] * 3, eps[s, :B], training=True)
+            ol = R.loss_endtoend(rs, xs, of, labels, margin=1.0, weightcontrastive=0.1)
+            ol["total_loss"].backward()
+            opt.step(Pr, {k: leaves[k].grad for k in names})
+            row = job.loss_log[s].cpu()
+            assert abs(float(row[13]) - float(ol["classification_loss"])) <= 1e-2 * abs(float(ol["classification_loss"])) + 1e-4, s
+    finally:
+        R.set_operand_rounding("fp32")
+    sd = job.state_dict()
+    for k in names:
+        assert float((sd[k] - Pr[k]).abs().max()) <= 2.0 * lr * 2 + 1e-6, k
