@@ -97,6 +97,7 @@ struct Ctx {
   float* bgrad;      // [128] bias gradients of the current weight-gradient pass (the ones column), see wgrad_adam
   unsigned* abort;   // [1] set by split_handoff on a time-out: the workgroup leaves the launch
   unsigned long long* tlast;   // [8] last stamp per wave (NM_F_TRACE)
+  int wave_s;        // wave index of this wavefront inside the workgroup (wave-uniform, set once at kernel entry)
   int tid, lane, wave, wm, wn, g, c16;
   int row0;          // first table row of this tile
   int nrows;         // valid rows in this tile (<= 256)
@@ -156,30 +157,32 @@ enum { PH_ENC_L0 = 0, PH_ENC_REST, PH_HEADS, PH_LATENT, PH_DEC_ZC, PH_DEC_HID, P
 __device__ __forceinline__ void tr(const Ctx& c, int tag) {
   if ((c.flags & 64) && blockIdx.x == 0 && blockIdx.y == 0) {
     unsigned long long t = clock64();
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = c.wave_s;
     nm_trace_cycles[w][tag] += t - c.tlast[w];
     c.tlast[w] = t;
   }
 }
 __device__ __forceinline__ void prof(Ctx& c, int phase) {
-  if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 &&
-      __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+  if ((c.flags & NM_F_PROFILE) && blockIdx.x == 0 && blockIdx.y == 0 && c.wave_s == 0) {
     unsigned long long t = clock64();
     nm_prof_cycles[phase] += t - c.t_last;
     c.t_last = t;
   }
 }
 
-// Re-derive the lane/wave indices from an opaque copy of threadIdx.x.  Without this the compiler
-// hoists every per-lane LDS/global address of every phase out of the persistent step loop and then
-// spills hundreds of them; re-deriving per phase keeps live ranges phase-local.  The wave index goes
-// through readfirstlane so that wave-level work splits compile to scalar branches.
+// Re-derive the lane/wave indices per phase from opaque copies.  Without this the compiler hoists every per-lane
+// LDS/global address of every phase out of the persistent step loop and then spills hundreds of them; re-deriving per
+// phase keeps live ranges phase-local.  The wave index is a scalar kept in the context (read once from threadIdx.x at
+// kernel entry), the lane index comes from mbcnt (EXEC is all ones wherever this is called): the workitem-id VGPR does
+// not have to stay alive across the whole step loop -- it was the one value the allocator spilled when a phase gained a
+// register.  Wave-level work splits compile to scalar branches.
 __device__ __forceinline__ void relaunder(Ctx& c) {
-  int t = threadIdx.x;
-  asm volatile("" : "+v"(t));
-  c.tid = t;
-  c.lane = t & 63;
-  int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  int w = c.wave_s;
+  asm volatile("" : "+s"(w));
+  c.lane = l;
+  c.tid = w * 64 + l;
   c.wave = w;
   c.wm = w / NWN;
   c.wn = w % NWN;
@@ -496,14 +499,34 @@ __device__ __forceinline__ Next blob_to_half(const Ctx& c, const GAS char* blob,
 }
 
 // ---- cooperative copies ----------------------------------------------------------------------
-// LDS tile [256][LDP] -> global activation image (same layout; the pad piece of every row is skipped)
-__device__ __forceinline__ void store_act_img(const Ctx& c, gbf16 dst, const __bf16* src) {
-#pragma unroll
-  for (int i = 0; i < (ROWS * 16) / WG; ++i) {
-    const int p = c.tid + i * WG, row = p >> 4, seg = p & 15;
+// Saved activations in the workspace: COMPACT, [256][nsegs * 8] bf16 with nsegs = act_segs(width) 16-byte segments per row
+// (the real columns + the ones column; 17 = the whole LDS row), reloaded into the [256][136] LDS layout by per-lane-address
+// LDS-DMA with the pad segments taken from the zero line of job.wsh (dma_act).  z | c | 1 is 5 segments of 17, a 110-wide
+// layer 14.
+__host__ __device__ inline int act_segs(int N) { const int s = rup(N + 1, 8) / 8; return s < LDP / 8 ? s : LDP / 8; }
+// store count a wave can rely on (lower bound: the iterations every thread takes part in)
+__host__ __device__ inline int act_stores(int nsegs) { return (ROWS * nsegs) / WG; }
+__device__ __forceinline__ void store_act_img(const Ctx& c, gbf16 dst, const __bf16* src, int nsegs) {
+  const float rs = 1.0f / (float)nsegs;
+#pragma unroll 2
+  for (int p = c.tid; p < ROWS * nsegs; p += WG) {
+    const int row = idiv(p, nsegs, rs), seg = p - row * nsegs;
     const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * LDP + seg * 8);
-    *(GAS u32x4*)(dst + row * LDP + seg * 8) = v;
+    *(GAS u32x4*)(dst + ((int64_t)row * nsegs + seg) * 8) = v;
   }
+}
+// rows [r0, r0 + nr) of a compact activation -> LDS at `dst` (= the LDS address of row r0); nr a multiple of 64
+__device__ __forceinline__ int dma_act(const Ctx& c, const GAS char* src, char* dst, int r0, int nr, int nsegs) {
+  const GAS char* zero = (const GAS char*)c.job->wsh;
+  int n = 0;
+  for (int p = c.wave; p < (nr * (LDP / 8)) >> 6; p += NWAVES) {
+    const int q = (p << 6) + c.lane;
+    const int r = idiv(q, LDP / 8, 8.0f / (float)LDP), sg = q - (LDP / 8) * r;
+    const GAS char* a = sg < nsegs ? src + (((int64_t)(r0 + r) * nsegs + sg) << 4) : zero;
+    dma16<0>(a, dst + (p << 10));
+    ++n;
+  }
+  return n;
 }
 // legacy [256][PW] workspace tiles (head kernels, fusion-backward hand-off)
 __device__ __forceinline__ void load_act(const Ctx& c, __bf16* dst, gcbf16 src, int width) {
@@ -662,8 +685,7 @@ __device__ __forceinline__ void act_to_P(const Ctx& c, const f32x4 (&acc)[2][RT]
 // by the PREVIOUS phase into half `half` of Q / vector slot `half`; this phase first requests `nx` (the next
 // phase's image), then waits for its own.  Optionally saved to `save` (activation image) for the backward pass.
 // `younger` = vector-memory operations this wave issued AFTER the request of this layer's image and before this call
-// (the previous phase's activation save: ACT_STORES): they may stay in flight.
-constexpr int ACT_STORES = (ROWS * 16) / WG;
+// (the previous phase's activation save: act_stores(..) of them at least): they may stay in flight.
 __device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& nx, int N, int K, bool act, gbf16 save,
                                           int younger) {
   Ctx c = cc;
@@ -693,7 +715,7 @@ __device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& n
   lds_barrier();                       // every wave has finished reading P
   act_to_P(c, acc, c.vec + half * (VEC_BYTES / 4), N, ntn, act);
   lds_barrier();
-  if (save) store_act_img(c, save, c.P);
+  if (save) store_act_img(c, save, c.P, act_segs(N));
 }
 
 // ---- GEMM phase: first encoder layer ----------------------------------------------------------
@@ -751,7 +773,7 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const GAS char* x
   }
   act_to_P(c, acc, bias, N, ntn, act);
   lds_barrier();
-  if (save) store_act_img(c, save, c.P);
+  if (save) store_act_img(c, save, c.P, act_segs(N));
   tr(c, 0);
 }
 
@@ -880,12 +902,12 @@ __device__ __forceinline__ void dgrad_hidden(const Ctx& cc, f32x4 (&acc)[2][RT],
   relaunder(c);
   char* Qb = reinterpret_cast<char*>(c.Q);
   dma_img(c, w_img, Qb, N, blob_kp(K), (const GAS char*)c.job->wsh);
-  const int n_hi = dma_lin(c, act_img + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
+  const int n_hi = dma_act(c, act_img, Qb + IMG_BYTES, ROWS / 2, ROWS / 2, act_segs(K));
   wait_vm(n_hi);
   lds_barrier();
   dgrad_tile(c, acc, c.P, LDP, 0, c.Q, LDP, wpad(N) / 32);
   lds_barrier();                              // weight image fully read
-  dma_lin(c, act_img, Qb, IMG_BYTES >> 10);   // waited for by the weight-gradient pass that follows (wgrad_adam, pending = 0)
+  dma_act(c, act_img, Qb, 0, ROWS / 2, act_segs(K));   // waited for by the weight-gradient pass that follows (wgrad_adam, pending = 0)
 }
 
 // P[r][k] = acc[k][r] * leaky_relu'(src[r][k]) for k < K, 0 for the ones/pad columns.
@@ -1358,13 +1380,13 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       gbf16 sv = save ? (gbf16)(ws_enc + (int64_t)(m * L + e) * ACT_BYTES) : (gbf16)nullptr;
       const GAS char* nxt = wsh + (e + 1 < L ? md.enc_s[e + 1] : md.heads_s);
       fwd_layer(c, half, blob_to_half(c, nxt, half ^ 1, e + 1 < L ? J->H[e + 1] : 2 * Zs, J->H[e]), J->H[e], J->H[e - 1], nl, sv,
-                save ? ACT_STORES : 0);
+                save ? act_stores(act_segs(J->H[e - 1])) : 0);
       half ^= 1;
     }
     tr(c, 1);
     prof(c, PH_ENC_REST);
     fwd_heads(c, half, no_next(), Z, J->H[L - 1], ws_mu_m + (int64_t)m * ROWS * Zs, ws_lv_m + (int64_t)m * ROWS * Zs, Zs,
-              save ? ACT_STORES : 0, fastlat ? zlds : (__bf16*)nullptr, step, vec4, &kl_fast);
+              save ? act_stores(act_segs(J->H[L - 1])) : 0, fastlat ? zlds : (__bf16*)nullptr, step, vec4, &kl_fast);
     prof(c, PH_HEADS);
   }
 
@@ -1532,7 +1554,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     if (MODE == 2) {
       // second pass: the last hidden activation comes back from the workspace, chunk 0 of the output layer with it
       lds_barrier();                                   // P / S are drained by whatever ran before
-      dma_lin(c, ws_dec + (int64_t)(L - 1) * ACT_BYTES, Pb, ACT_BYTES >> 10);
+      dma_act(c, ws_dec + (int64_t)(L - 1) * ACT_BYTES, Pb, 0, ROWS, act_segs(J->H[0]));
       dma_lin(c, oblob, Sb, OBLOB_BYTES >> 10);
     } else {
     if (m > 0 && !split) issue_next(c, blob_to_half(c, wsh + md.dec_s[0], 0, J->H[L - 1], Z + C));
@@ -1540,9 +1562,9 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       build_zc(c, c.P, md, ws_mu_j, ws_es, Z, C, Zs, S, ws_mu_m + (int64_t)min(m, Me - 1) * ROWS * Zs,
                fastlat ? zlds : (const __bf16*)nullptr);
       lds_barrier();
-      if (save || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P);
+      if (save || reuse_zc) store_act_img(c, (gbf16)ws_zc, c.P, act_segs(Kd0));
     } else {
-      dma_lin(c, ws_zc, Pb, ACT_BYTES >> 10);          // waited for by the first layer (it waits for everything older)
+      dma_act(c, ws_zc, Pb, 0, ROWS, act_segs(Kd0));   // waited for by the first layer (it waits for everything older)
     }
     tr(c, 4);
     prof(c, PH_DEC_ZC);
@@ -1555,7 +1577,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       Next nx = (d + 1 < L) ? blob_to_half(c, wsh + md.dec_s[d + 1], half ^ 1, J->H[L - 2 - d], Nout)
                             : Next{oblob, Sb, OBLOB_BYTES >> 10, nullptr, nullptr, 0, 0};
       // (d == 0: the z | c | 1 build / reload sits between the image request and here -- wait for everything)
-      fwd_layer(c, half, nx, Nout, Kin, nl, sv, (d > 0 && save) ? ACT_STORES : 0);
+      fwd_layer(c, half, nx, Nout, Kin, nl, sv, (d > 0 && save) ? act_stores(act_segs(Kin)) : 0);
       half ^= 1;
     }
     }
@@ -2107,7 +2129,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     // P <- [d mu_m | 0 | d logvar_m | 0] is put together
     const GAS char* act_last = ws_enc + (int64_t)(m * L + (L - 1)) * ACT_BYTES;
     dma_img(c, wsh + md.heads_s, Qb, 2 * Zs, blob_kp(Hh), (const GAS char*)J->wsh);
-    dma_lin(c, act_last + IMG_BYTES, Qb + IMG_BYTES, IMG_BYTES >> 10);
+    dma_act(c, act_last, Qb + IMG_BYTES, ROWS / 2, ROWS / 2, act_segs(Hh));
     if (once || once_ws) {                         // this expert's columns of the saved fusion backward
       const int segs = (2 * Zs) >> 3;              // 16-byte pieces per row
       const float rs_ = 1.0f / (float)segs;
@@ -2217,7 +2239,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     dgrad_tile(c, acc, c.P, LDP, 0, c.Q, LDP, (2 * Zs) / 32);
     lds_barrier();                                  // image fully read
     prof(c, PH_ENCB_HEADS_DGRAD);
-    dma_lin(c, act_last, Qb, IMG_BYTES >> 10);   // (waited for inside the first weight-gradient pass)
+    dma_act(c, act_last, Qb, 0, ROWS / 2, act_segs(Hh));   // (waited for inside the first weight-gradient pass)
     tr(c, 13);
     {
       GAS char* img = wsh + md.heads_s;
@@ -2284,6 +2306,7 @@ static_assert(XIMG_BYTES + OBLOB_BYTES + NWAVES * PATCH_FLOATS * 4 <= ACT_BYTES,
 static_assert(2 * XIMG_BYTES - ACT_BYTES <= SPATCH_OFF && SPATCH_OFF + NWAVES * PATCH_FLOATS * 4 <= STAGE_FLOATS * 4, "S layout");
 
 __device__ __forceinline__ void carve_lds(Ctx& c, unsigned char* smem) {
+  c.wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   c.P = reinterpret_cast<__bf16*>(smem);
   c.Q = c.P + ROWS * LDP;
   c.stage = reinterpret_cast<float*>(c.Q + ROWS * LDP);
@@ -2361,7 +2384,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
     if (flags & NM_F_PROFILE) c.t_last = clock64();
-    if (flags & 64) c.tlast[threadIdx.x >> 6] = clock64();
+    if (flags & 64) c.tlast[c.wave_s] = clock64();
     lds_barrier();
     relaunder(c);
     run_step<SCALAR_TR, MODE>(c, s);
@@ -2371,7 +2394,7 @@ __global__ __launch_bounds__(WG) void nm_step_kernel(const nm_job_t* __restrict_
     handoff_barrier();
     tr(c, 63);
   }
-  if ((flags & 64) && blockIdx.y == 0 && blockIdx.x < 512 && threadIdx.x == 0) nm_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+  if ((flags & 64) && blockIdx.y == 0 && blockIdx.x < 512 && c.tid == 0) nm_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 }
 
 #include "nm_wide.inc"
@@ -2518,7 +2541,7 @@ __device__ __forceinline__ void reg_head_body(Ctx& c, const nm_job_t* J, int ste
     apply_grad(c, J->reg_b[1] + c.tid, g);
   }
   // layer 2 backward: Q <- h1; delta h1 (pre-mask) = delta h2 W2; dW2 = delta h2^T h1
-  dma_lin(c, (const GAS char*)ws_h1, Qb, ACT_BYTES >> 10);
+  dma_act(c, (const GAS char*)ws_h1, Qb, 0, ROWS, act_segs(N1));
   wait_vm(0);
   lds_barrier();
   zero_acc(acc);
@@ -3038,7 +3061,7 @@ __global__ __launch_bounds__(WG) void nm_head_step_kernel(const nm_job_t* __rest
     const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
     c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
     c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
-    if (flags & 64) c.tlast[threadIdx.x >> 6] = clock64();
+    if (flags & 64) c.tlast[c.wave_s] = clock64();
     lds_barrier();
     relaunder(c);
     c.flags = NM_F_EXPORT | tflags;

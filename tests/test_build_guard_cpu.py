@@ -40,7 +40,7 @@ def test_kernel_isa_has_no_spill_ahead_of_exec_restore_and_step_kernel_does_not_
     assert m.main() == 0
     for fam in ("nm_step_kernel", "nm_wide_step_kernel"):
         assert m.LIMITS[fam]["vgpr_spill_count"] == 0 and m.LIMITS[fam]["private_segment_fixed_size"] == 0
-        assert m.LIMITS[fam]["sgpr_spill_count"] <= 520
+        assert m.LIMITS[fam]["sgpr_spill_count"] <= 540
     assert m.LIMITS["nm_head_step_kernel"]["vgpr_spill_count"] == 0 and m.LIMITS["nm_head_step_kernel"]["private_segment_fixed_size"] <= 96
 
 
