@@ -467,7 +467,10 @@ class JobSet:
         scale = float(os.environ.get("NMHIP_DEPHASE_SCALE", "1"))
         n = len(self.jobs)
         key = (mode, scale, n)
-        if getattr(self, "_dephase_key", None) == key:          # (host time of a launch matters: it precedes the launch)
+        vals = getattr(self, "_dephase_vals", None)
+        # (host time of a launch matters: it precedes the launch -- so the offsets are computed once per set; a job that
+        #  another set has re-timed in between is noticed by comparing the values this set assigned)
+        if getattr(self, "_dephase_key", None) == key and vals is not None and all(j.dephase_sleeps == v for j, v in zip(self.jobs, vals)):
             return
         self._dephase_key = key
         for b, j in enumerate(self.jobs):
@@ -484,6 +487,7 @@ class JobSet:
             if s != j.dephase_sleeps:
                 j.dephase_sleeps = s
                 j._version += 1
+        self._dephase_vals = [j.dephase_sleeps for j in self.jobs]
 
     def _upload(self, n_tiles: int = 1):
         """Descriptor array on the device; rebuilt only when a job's descriptor changed (the
