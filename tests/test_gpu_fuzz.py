@@ -37,6 +37,32 @@ def test_random_shape_matches_oracle(seed):
              ll32_tol=1e-4 * max(1.0, (256.0 / B) ** 0.5))
 
 
+def _draw_wide(seed):
+    """Shapes beyond the fused kernel's tile: up to 5 layers of up to 400 columns, latent up to 128."""
+    rng = np.random.default_rng(5000 + seed)
+    M = int(rng.integers(1, 4))
+    L = int(rng.integers(1, 6))
+    dims = [int(rng.integers(3, 300)) for _ in range(M)]
+    hidden = [int(rng.integers(8, 400)) for _ in range(L)]
+    c_dim = int(rng.integers(3, 30))
+    Z = int(rng.integers(1, 129))
+    if all(h <= 127 for h in hidden) and Z <= 64 and Z + c_dim <= 127:
+        hidden[int(rng.integers(0, L))] = int(rng.integers(128, 400))       # make sure it IS a general-shape model
+    B = int(rng.choice([1, 19, 83, 200, 256]))
+    combine = str(rng.choice(["poe", "gpoe", "moe", "mopoe"]))
+    return dims, Z, combine, B, hidden, c_dim, bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_wide_shape_matches_oracle(seed):
+    """The same comparison on the general-shape path (nm_launch_wide): block boundaries at 128 columns in every position
+    (partial last blocks, latent > 64, latent + c_dim > 127, deeper stacks)."""
+    dims, Z, combine, B, hidden, c_dim, non_linear = _draw_wide(seed)
+    job = run_case(dims, Z, combine, B, seed=seed, hidden=tuple(hidden), c_dim=c_dim, non_linear=non_linear,
+                   ll32_tol=1e-4 * max(1.0, (256.0 / B) ** 0.5))
+    assert job.spec.wide
+
+
 @pytest.mark.parametrize("seed", range(100, 110))
 def test_random_shape_fused_adam_steps(seed):
     """Three fused train steps (forward + ELBO + backward + Adam inside the kernel, one launch, the batch index
