@@ -723,10 +723,26 @@ __device__ __forceinline__ void fwd_layer(const Ctx& cc, int half, const Next& n
 // images (xb chunk [256][LDX], weight chunk [128][LDX]); two stages (one in P, one in Q: both are dead here), so
 // chunk i + 1 is in flight while chunk i is multiplied.  The last chunk sits in P; `nx` (the next layer's image,
 // into Q) is requested as soon as the Q stage is drained.
-// (xsrc: the tile's chunk images [nch][256][LDX]; wsrc: the layer's chunk images [nch][128][LDX] followed by the bias
-//  piece.  The trunk's encoders and the regression head's first layer both run through here.)
+// (xsrc: the tile's chunk images [nch][256][LDX]; wsrc: the layer's weights -- compact = false: chunk images
+//  [nch][128][LDX] followed by the bias piece (the regression head's first layer); compact = true: the matrix itself,
+//  [N rounded to 16][Kx] bf16 row-major, then the bias piece (l0_img_bytes): the trunk's encoders, each chunk gathered into
+//  its [128][LDX] stage by per-lane-address copies with the pad rows / the pad segment taken from the zero line.)
+__host__ __device__ inline int l0_img_bytes(int N, int Kx) { return rup(rup(N, 16) * Kx * 2, 1024); }
+__device__ __forceinline__ int dma_w0chunk(const Ctx& c, const GAS char* w, char* dst, int N, int Kx, int i) {
+  const GAS char* zero = (const GAS char*)c.job->wsh;
+  int n = 0;
+  for (int p = c.wave; p < (W0IMG_BYTES >> 10); p += NWAVES) {
+    const int q = (p << 6) + c.lane;
+    const int r = idiv(q, LDX / 8, 8.0f / (float)LDX), sg = q - (LDX / 8) * r;
+    const int k = i * XCH + sg * 8;
+    const GAS char* a = (r < N && sg < XCH / 8 && k < Kx) ? w + (((int64_t)r * Kx + k) << 1) : zero;
+    dma16<0>(a, dst + (p << 10));
+    ++n;
+  }
+  return n;
+}
 __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const GAS char* xsrc, int Kx, const GAS char* wsrc, const Next& nx,
-                                                int N, bool act, gbf16 save) {
+                                                int N, bool act, gbf16 save, bool compact = false) {
   Ctx c = cc;
   relaunder(c);
   const int nch = (Kx + XCH - 1) / XCH;
@@ -736,12 +752,14 @@ __device__ __forceinline__ void fwd_first_layer(const Ctx& cc, const GAS char* x
   auto issue_chunk = [&](int i) {
     char* st = stage(i);
     int n = dma_lin<0>(c, xsrc + (int64_t)i * XIMG_BYTES, st, XIMG_BYTES >> 10);
-    n += dma_lin(c, wsrc + (int64_t)i * W0IMG_BYTES, st + XIMG_BYTES, W0IMG_BYTES >> 10);
+    n += compact ? dma_w0chunk(c, wsrc, st + XIMG_BYTES, N, Kx, i)
+                 : dma_lin(c, wsrc + (int64_t)i * W0IMG_BYTES, st + XIMG_BYTES, W0IMG_BYTES >> 10);
     return n;
   };
   int n_nxt = 0, n_blob = 0;
   issue_chunk(0);
-  if (c.wave == 3) dma16<0>(wsrc + (int64_t)nch * W0IMG_BYTES + (c.lane << 4), reinterpret_cast<char*>(bias));
+  if (c.wave == 3)
+    dma16<0>(wsrc + (compact ? (int64_t)l0_img_bytes(N, Kx) : (int64_t)nch * W0IMG_BYTES) + (c.lane << 4), reinterpret_cast<char*>(bias));
   if (nch > 1) n_nxt = issue_chunk(1);
   else n_blob = issue_next(c, nx);
   f32x4 acc[2][RT];
@@ -1373,7 +1391,7 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
     // (rows / inputs of that blob: the second encoder layer, or the heads' [mu | logvar] rows)
     const GAS char* after0 = wsh + (L > 1 ? md.enc_s[1] : md.heads_s);
     fwd_first_layer(c, (const GAS char*)asg(md.xb) + (int64_t)(c.row0 / ROWS) * ((md.Kx + XCH - 1) / XCH) * XIMG_BYTES, md.Kx,
-                    wsh + md.enc_s[0], blob_to_half(c, after0, 0, L > 1 ? J->H[1] : 2 * Zs, J->H[0]), J->H[0], nl, save0);
+                    wsh + md.enc_s[0], blob_to_half(c, after0, 0, L > 1 ? J->H[1] : 2 * Zs, J->H[0]), J->H[0], nl, save0, true);
     prof(c, PH_ENC_L0);
     int half = 0;
     for (int e = 1; e < L; ++e) {
@@ -2281,8 +2299,8 @@ __device__ __forceinline__ void run_step(Ctx& c, int step) {
       dma_lin<0>(c, xsrc, Qb, XIMG_BYTES >> 10);
       auto geom = [&](int kc) {
         return WgGeom{N0, K0, kc * XCH, min(XCH, Kx - kc * XCH),
-                      WgT{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * W0IMG_BYTES, LDX * 2,
-                          (GAS float*)(img + (int64_t)nch * W0IMG_BYTES), spatch}};
+                      WgT{md.enc_w[0], md.enc_b[0], img + (int64_t)kc * XCH * 2, Kx * 2,
+                          (GAS float*)(img + l0_img_bytes(N0, Kx)), spatch}};
       };
       // chunk kc + 1 is requested as soon as every wave is done with chunk kc - 1 (the barrier that ends pass kc - 1) and
       // lands during pass kc; pass kc waits for chunk kc itself, after its own first requests (pending = what this
@@ -3147,8 +3165,8 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
     const nm_modality_t& md = J->mod[m];
     if (m < Me) {
       const int nch = (md.Kx + XCH - 1) / XCH;
-      sync_matrix(prm, md.enc_w[0], J->H[0], md.D + C, wsh + md.enc_s[0], LDX * 2, XCH, W0IMG_BYTES, BIG, 0);
-      float* b0 = (float*)(wsh + md.enc_s[0] + (int64_t)nch * W0IMG_BYTES);
+      sync_matrix(prm, md.enc_w[0], J->H[0], md.D + C, wsh + md.enc_s[0], md.Kx * 2, BIG, 0, BIG, 0);
+      float* b0 = (float*)(wsh + md.enc_s[0] + l0_img_bytes(J->H[0], md.Kx));
       for (int i = sh_tid(); i < J->H[0]; i += sh_nthr()) b0[i] = prm[md.enc_b[0] + i];
       for (int e = 1; e < L; ++e) {
         sync_matrix(prm, md.enc_w[e], J->H[e], J->H[e - 1], wsh + md.enc_s[e], blob_kp(J->H[e - 1]) * 2, BIG, 0, BIG, 0);
@@ -3450,7 +3468,7 @@ int64_t nm_fill_shadow(nm_job_t* j) {
     md.heads_s = 0;
     if (m < Me) {
       const int nch = (md.Kx + XCH - 1) / XCH;
-      md.enc_s[0] = o; o += (int64_t)nch * W0IMG_BYTES + VEC_BYTES;
+      md.enc_s[0] = o; o += (int64_t)l0_img_bytes(j->H[0], md.Kx) + VEC_BYTES;
       for (int e = 1; e < L; ++e) { md.enc_s[e] = o; o += cblob_bytes(j->H[e], j->H[e - 1]); }
       md.heads_s = o; o += cblob_bytes(2 * Zs, j->H[L - 1]);
     }

@@ -96,8 +96,10 @@ def test_shadow_layout(lib):
         md = j.mod[m]
         offs += [md.enc_s[0], md.enc_s[1], md.heads_s, md.dec_s[0], md.dec_s[1], md.out_s]
     assert offs == sorted(offs) and len(set(offs)) == len(offs) and all(o % 1024 == 0 for o in offs)
-    # 7 chunk images [128][72] + 1 KiB of vectors for the first encoder layer of a 379 + 29 + 1 wide input
-    assert j.mod[0].enc_s[1] - j.mod[0].enc_s[0] == 7 * 128 * 72 * 2 + 1024
+    # the first encoder layer of a 379 + 29 + 1 wide input: the matrix compact, [112][416] bf16, + 1 KiB of vectors
+    assert j.mod[0].enc_s[1] - j.mod[0].enc_s[0] == 112 * 416 * 2 + 1024
+    # ... a hidden 110 x 110 layer: [112][112] bf16 rounded to 1 KiB + 1 KiB of vectors (round 2: a 35 KiB padded image)
+    assert j.mod[0].heads_s - j.mod[0].enc_s[1] == 25 * 1024 + 1024
     # 6 output chunk blobs of 18 KiB for 379 ROI
     assert j.mod[1].enc_s[0] - j.mod[0].out_s == 6 * 18432
     assert lib.nm_xb_elems(1024, 416) == 1024 * 7 * 72
