@@ -86,11 +86,13 @@ typedef struct nm_modality {
   int64_t out_w, out_b;                           /* decoder_mean_layer                   */
   int64_t alpha;                                  /* alpha_m_list.{m} or -1               */
   /* byte offsets of this modality's bf16 shadow images inside job.wsh (filled by nm_fill_shadow): the weights the
-   * forward / dgrad GEMMs read, laid out exactly as the LDS tiles, rewritten by the Adam sweep              */
-  int64_t enc_s[NM_MAX_HID];                      /* [0]: ceil(Kx/64) chunk images [128][72] + bias; others [128][136] + bias */
-  int64_t heads_s;                                /* [128][136]: rows [0,Z) mean head, [Zs,Zs+Z) logvar head; + biases */
-  int64_t dec_s[NM_MAX_HID];                      /* [128][136] + bias                                              */
-  int64_t out_s;                                  /* ceil(D/64) chunk blobs: [64][136] + bias[64] + logvar_out[64]   */
+   * forward / dgrad GEMMs read, rewritten by the Adam sweep.  Matrices are stored COMPACT -- [rows rounded to 16][kp] bf16
+   * row-major, kp = max(K + 1 rounded to 8, K rounded to 16), rounded to 1 KiB -- followed by a 1-KiB fp32 vector piece;
+   * the LDS-DMA copy gathers them into the padded LDS tiles (pads from the 1 KiB of zeros job.wsh starts with)  */
+  int64_t enc_s[NM_MAX_HID];                      /* [0]: [H0 rounded to 16][Kx] + bias piece; others compact + bias piece */
+  int64_t heads_s;                                /* rows [0,Z) mean head, [Zs,Zs+Z) logvar head (Zs = Z rounded to 16); + biases */
+  int64_t dec_s[NM_MAX_HID];                      /* compact + bias piece                                            */
+  int64_t out_s;                                  /* ceil(D/64) chunk blobs of 18 KiB: [64][136] + bias[64] + logvar_out[64] */
   /* optional per-row exports (NM_F_EXPORT), indexed by absolute table row; may be NULL */
   float* out_loc;         /* [rows_alloc][x_pitch]  decoder mean x_hat (pad columns 0)   */
   float* out_sqerr;       /* [rows_alloc][x_pitch]  (x - x_hat)^2        (pad columns 0)   */
