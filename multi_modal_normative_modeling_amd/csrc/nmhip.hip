@@ -3549,7 +3549,7 @@ int nm_launch_wide(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_pe
   if (n_tiles > 1 && (flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return -8;
   hipError_t e = hipFuncSetAttribute((const void*)nm_wide_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
   if (e != hipSuccess) return (int)e;
-  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_EXPORT | NM_F_ZGIVEN);
+  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_EXPORT | NM_F_ZGIVEN | NM_F_TRACE);
   hipLaunchKernelGGL(nm_wide_step_kernel, dim3(n_jobs, n_tiles), dim3(WG), SMEM_BYTES, (hipStream_t)stream, jobs_dev, step0,
                      steps_per_tile, flags);
   return (int)hipGetLastError();

@@ -55,3 +55,16 @@ def test_resource_parser():
     r = _mod().resources(txt)
     assert list(r.values())[0] == {"private_segment_fixed_size": 268, "sgpr_spill_count": 201, "vgpr_count": 256,
                                    "vgpr_spill_count": 88}
+
+
+def test_build_tracks_included_files():
+    """build() must notice an edit of a file the library's sources #include (nm_wide.inc): the staleness check once looked
+    at the .hip files only and kept a stale library after such an edit."""
+    import inspect
+    import re
+    import __graft_entry__ as ge
+    inc = set()
+    for src in ge.SOURCES:
+        inc |= set(re.findall(r'#include "([^"]+\.inc)"', src.read_text()))
+    assert inc and all((ge.PKG / "csrc" / i).exists() for i in inc)
+    assert '"*.inc"' in inspect.getsource(ge.build)

@@ -13,7 +13,12 @@ TAGS = {0: "enc L0 fwd", 1: "enc hidden fwd", 2: "enc heads", 3: "latent + KL", 
         20: "pass-1 hand-off", 21: "reg head: layer 1 fwd", 22: "reg head: layers 2-3 + MSE", 23: "reg head: bwd layers 3-2",
         24: "reg head: L1 wgrad+adam", 25: "reg head: L1 d x_hat (dgrad)", 26: "cls head: hidden fwd", 27: "cls head: out + CE + hinge",
         29: "head tail (cls: backward) + hand-off", 30: "cls fwd: input save + bias + GEMM", 31: "cls fwd: batch statistics",
-        32: "cls fwd: BN / ReLU / dropout epilogue"}
+        32: "cls fwd: BN / ReLU / dropout epilogue",
+        # general-shape path (nm_wide.inc)
+        40: "wide enc L0 fwd", 41: "wide enc hidden fwd", 42: "wide enc heads", 43: "wide fusion + KL", 44: "wide z|c tiles: hand-off",
+        45: "wide dec hidden fwd", 46: "wide out fwd + NLL + delta", 48: "wide dgrad parts (all layers)", 49: "wide out wgrad+adam",
+        51: "wide dec hidden wgrad+adam", 52: "wide fusion bwd", 53: "wide enc heads dgrad", 54: "wide enc heads wgrad+adam",
+        55: "wide enc hidden wgrad+adam", 56: "wide enc L0 wgrad+adam", 57: "wide z|c tiles: set-up", 58: "wide z|c tiles: loop"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--jobs", type=int, default=1)
 ap.add_argument("--steps", type=int, default=16)
@@ -21,6 +26,7 @@ ap.add_argument("--procedure", default="SM-T1w_sMRI")
 ap.add_argument("--forward", action="store_true", help="trace the forward-only export launch over all row tiles (deviation pass)")
 ap.add_argument("--head", choices=["", "regression", "endtoend"], default="",
                 help="trace the head-model launch (nm_train_steps_head) of 3 x 379 regression / config-5 end-to-end jobs")
+ap.add_argument("--wide", default="", help="general-shape path: '-H'-style list, e.g. '110 110 100' (hidden widths, then the latent)")
 a = ap.parse_args()
 cohort = prep.synthetic_cohort(n=1280, d=379)
 lib = _lib.load()
@@ -54,7 +60,16 @@ if a.head:
     lib.nm_trace_read(buf, 1)
     js._train_head(js.jobs[0].step, a.steps, _lib.NM_F_TRACE)
 else:
-    jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, a.jobs, "cuda:0")
+    if a.wide:
+        hz = [int(v) for v in a.wide.split()]
+        mods, _ = workload.procedure_modalities(a.procedure)
+        folds = prep.kfold_indices(len(cohort.iid), 5, 42)
+        xs, cc = prep.fold_train_tables(cohort, mods, folds[0][0])
+        tabs = [nm.Table(x, cc, "cuda:0") for x in xs]
+        spec = nm.ModelSpec([t.D for t in tabs], hz[:-1], hz[-1], 29)
+        jobs = [nm.Job(spec, tabs, combine="gpoe", seed=j, init_seed=42 + j, loss_cap=8) for j in range(a.jobs)]
+    else:
+        jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, a.jobs, "cuda:0")
     js = nm.JobSet(jobs)
     js.train(4); torch.cuda.synchronize()
     if a.forward:
