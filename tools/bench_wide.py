@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU diagnostic: train-step throughput of the general-shape path (nm_launch_wide) at shapes of the reference's sweeps, next to
 the fused kernel at the default shape (256 models each, one workgroup per model)."""
-import sys, time
+import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
@@ -20,7 +20,7 @@ for name, mods, hidden, Z, jobs in (("fused  SE 3x379 [110,110]/10", 3, [110, 11
     spec = nm.ModelSpec([379] * mods, hidden, Z, 29)
     js = nm.JobSet([nm.Job(spec, tabs[:mods], combine="gpoe", seed=j, init_seed=42 + j, loss_cap=8) for j in range(jobs)])
     js.train(2); torch.cuda.synchronize()
-    n = 16 if spec.wide else 64
+    n = int(os.environ.get("NM_WIDE_STEPS", "64"))
     t0 = time.perf_counter(); js.train(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     js.assert_finite()
     w = workload.step_work(spec.input_dims, hidden=hidden, latent=Z)
