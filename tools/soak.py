@@ -11,9 +11,25 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--procedure", default="SE-gPoE")
 ap.add_argument("--steps", type=int, default=2048)
 ap.add_argument("--lr", type=float, default=1e-3)
+ap.add_argument("--wide", default="", help="general-shape path: '-H'-style list, e.g. '300 300 30'")
 a = ap.parse_args()
 cohort = prep.synthetic_cohort(n=1280, d=379)
-jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, 256, "cuda:0", lr=a.lr)
+if a.wide:
+    hz = [int(v) for v in a.wide.split()]
+    mods, combine = workload.procedure_modalities(a.procedure)
+    folds = prep.kfold_indices(len(cohort.iid), 5, 42)
+    tabs = {}
+    jobs = []
+    for j in range(256):
+        k = j % 5
+        if k not in tabs:
+            xs, cc = prep.fold_train_tables(cohort, mods, folds[k][0])
+            tabs[k] = [nm.Table(x, cc, "cuda:0") for x in xs]
+        spec = nm.ModelSpec([t.D for t in tabs[k]], hz[:-1], hz[-1], 29)
+        assert spec.wide
+        jobs.append(nm.Job(spec, tabs[k], combine=combine, lr=a.lr, seed=j, init_seed=42 + j, loss_cap=64))
+else:
+    jobs = workload.build_sweep_jobs(cohort, a.procedure, 5, 256, "cuda:0", lr=a.lr)
 js = nm.JobSet(jobs)
 first = None
 done = 0
