@@ -12,7 +12,7 @@ from pathlib import Path
 NM_MAX_MOD = 8
 NM_MAX_EXP = 4
 NM_MAX_HID = 8
-NM_MAX_CLS = 3
+NM_MAX_CLS = 5
 NM_MAX_CLASSES = 4
 NM_BATCH = 256
 NM_MAX_WIDTH = 127

@@ -2650,10 +2650,18 @@ __global__ __launch_bounds__(WG) void nm_reghead_kernel(const nm_job_t* __restri
 // class logits; cross entropy (mean over rows) and the contrastive hinge on the per-subject deviations the
 // trunk exported.  Backward returns d CE / d z (dz_out) and, per decoder, the row coefficient of the hinge
 // gradient (rowcoef_out), and applies / stores the classifier's own gradients.
+// classifier workspace of one tile: the blocks' inputs hin[0 .. NM_MAX_CLS] (bf16 [256][128]), the normalised activations
+// xhat[i] (fp32 [256][128]) and 1 / sigma rstd[i] (fp32 [128]) of every BatchNorm -- addresses computed, not tabulated: a
+// pointer table indexed by the block number is a private-memory array for this compiler
 struct ClsWs {
-  gbf16 hin[NM_MAX_CLS + 1];
-  gf32 xhat[NM_MAX_CLS];
-  gf32 rstd[NM_MAX_CLS];
+  GAS char* base;
+  __device__ __forceinline__ gbf16 hin(int i) const { return (gbf16)(base + (int64_t)i * ROWS * PW * 2); }
+  __device__ __forceinline__ gf32 xhat(int i) const {
+    return (gf32)(base + (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)i * ROWS * PW * 4);
+  }
+  __device__ __forceinline__ gf32 rstd(int i) const {
+    return (gf32)(base + (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)NM_MAX_CLS * ROWS * PW * 4 + (int64_t)i * PW * 4);
+  }
 };
 __host__ __device__ inline int64_t cls_ws_bytes() {
   return (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)NM_MAX_CLS * ROWS * PW * 4 + (int64_t)NM_MAX_CLS * PW * 4;
@@ -2693,13 +2701,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
   gcf32 prm = asg(J->params);
   float* col1 = c.colacc;
   float* col2 = c.stage;
-  ClsWs W;
-  {
-    GAS char* p = hws;
-    for (int i = 0; i <= NM_MAX_CLS; ++i) { W.hin[i] = (gbf16)p; p += (int64_t)ROWS * PW * 2; }
-    for (int i = 0; i < NM_MAX_CLS; ++i) { W.xhat[i] = (gf32)p; p += (int64_t)ROWS * PW * 4; }
-    for (int i = 0; i < NM_MAX_CLS; ++i) { W.rstd[i] = (gf32)p; p += (int64_t)PW * 4; }
-  }
+  const ClsWs W{hws};
   const float keep_scale = (train && J->cls_dropout > 0.f) ? 1.0f / (1.0f - J->cls_dropout) : 1.0f;
 
   // ---- P <- z (or the joint mean for predict) ----
@@ -2749,7 +2751,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
         gam[t][i] = prm[J->cls_bn_w[li] + fc];
         bet[t][i] = prm[J->cls_bn_b[li] + fc];
       }
-    if (bwd) store_act(c, W.hin[li], c.P, K32);
+    if (bwd) store_act(c, W.hin(li), c.P, K32);
     bias_acc(c, acc, prm + J->cls_b[li], N, 0);
     wblk_store<128>(c, wb, c.Q, LDP, N, K, 0, 0);
     lds_barrier();
@@ -2808,7 +2810,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
       }
     if (c.tid < N && train) {                      // per-feature rstd for the backward pass; running statistics
       const float m = col1[c.tid] / Bf, var = col2[c.tid] / Bf;
-      if (bwd) W.rstd[li][c.tid] = 1.0f / sqrtf(var + 1e-5f);
+      if (bwd) W.rstd(li)[c.tid] = 1.0f / sqrtf(var + 1e-5f);
       if (bn_stats && log) {
         gf32 rm = asg(J->params) + J->cls_bn_mean[li] + c.tid, rv = asg(J->params) + J->cls_bn_var[li] + c.tid;
         const float unb = c.nrows > 1 ? var * Bf / (Bf - 1.0f) : var;      // running_var takes the unbiased estimate
@@ -2834,7 +2836,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
           if (train && J->cls_dropout > 0.f) h = u4[i] >= J->cls_dropout ? h * keep_scale : 0.f;
           pk[i] = (__bf16)((f0 + i < N && r < c.nrows) ? h : 0.f);
         }
-        if (bwd) *(GAS f32x4*)(W.xhat[li] + r * PW + f0) = xh;
+        if (bwd) *(GAS f32x4*)(W.xhat(li) + r * PW + f0) = xh;
         *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
       }
     }
@@ -2846,7 +2848,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
   relaunder(c);
   const int Kl = Lc ? J->cls_width[Lc - 1] : Z, Kl32 = rup(Kl, 32);
   gcf32 Wo = prm + J->cls_w[Lc];
-  if (bwd) store_act(c, W.hin[Lc], c.P, Kl32);
+  if (bwd) store_act(c, W.hin(Lc), c.P, Kl32);
   bias_acc(c, acc, prm + J->cls_b[Lc], C, 0);
   for (int ks = 0; ks < Kl32 / 32; ++ks) {
     bf16x8 wf[2];
@@ -2928,7 +2930,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
 
   // ---- backward: output layer ----
   relaunder(c);
-  load_act(c, c.Q, W.hin[Lc], Kl32);
+  load_act(c, c.Q, W.hin(Lc), Kl32);
   lds_barrier();
   zero_acc(acc);
   dgrad_acc(c, acc, c.P, Wo, C, Kl, 1, 0);
@@ -2951,7 +2953,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int fc = min((c.wn + 4 * t) * 16 + 4 * c.g + i, N - 1);
-        grs[t][i] = prm[J->cls_bn_w[li] + fc] * W.rstd[li][fc];
+        grs[t][i] = prm[J->cls_bn_w[li] + fc] * W.rstd(li)[fc];
       }
     if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
     __syncthreads();
@@ -2966,7 +2968,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
       for (int rt = 0; rt < RT; ++rt) {
         const int r = c.wm * WROWS + rt * 16 + c.c16;
         const bf16x4 h = *reinterpret_cast<const bf16x4*>(c.Q + r * LDP + f0);
-        const f32x4 xh = *(const GAS f32x4*)(W.xhat[li] + r * PW + f0);
+        const f32x4 xh = *(const GAS f32x4*)(W.xhat(li) + r * PW + f0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float dy = ((float)h[i] > 0.f && r < c.nrows && f0 + i < N) ? acc[t][rt][i] * keep_scale : 0.f;
@@ -2994,7 +2996,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const int r = c.wm * WROWS + rt * 16 + c.c16;
-        const f32x4 xh = *(const GAS f32x4*)(W.xhat[li] + r * PW + f0);
+        const f32x4 xh = *(const GAS f32x4*)(W.xhat(li) + r * PW + f0);
         bf16x4 pk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -3009,7 +3011,7 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
       apply_grad(c, J->cls_bn_w[li] + c.tid, col2[c.tid]);
       apply_grad(c, J->cls_bn_b[li] + c.tid, col1[c.tid]);
     }
-    load_act(c, c.Q, W.hin[li], K32);
+    load_act(c, c.Q, W.hin(li), K32);
     lds_barrier();
     float gbi = 0.f;
     if (c.tid < N) for (int r = 0; r < ROWS; ++r) gbi += (float)c.P[r * LDP + c.tid];
@@ -3335,7 +3337,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 7; }
+int nm_version(void) { return 8; }
 
 /* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {

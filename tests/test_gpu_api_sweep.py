@@ -213,8 +213,11 @@ def test_regression_and_endtoend_command_lines_one_gpu():
         # an -H list of the end-to-end grid beyond the fused tile (commands_list9_endtoend.sh:24) and one of its -Layers lists
         res = sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-H", "300", "300", "30", "-Layers", "128", "64"])
         assert len(res) == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
-        with pytest.raises(ValueError):                          # a classifier deeper than the head kernel takes
-            sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "128", "64", "32", "16"])
+        # "-Layers 128 64 32 16" of the same grid (four blocks: NM_MAX_CLS = 5) ...
+        res = sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "128", "64", "32", "16"])
+        assert len(res) == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
+        with pytest.raises(ValueError):                          # ... and a classifier wider than the head kernel takes
+            sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "256", "128", "64"])
 
 
 def test_train_then_test_command_lines():
@@ -457,15 +460,18 @@ def test_fused_endtoend_training_matches_reference_trajectory():
             assert float((sd[k] - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, k
 
 
-@pytest.mark.parametrize("dims,hidden,cdim,B", [([60, 45, 70], [40, 32], 5, 200), ([379, 379, 379], [110, 110], 29, 256),
-                                                 ([60, 45, 70], [300, 160], 5, 200)])      # "-H 300 300 ..": the trunk on the general-shape path
-def test_classifier_head_config5_shape_vs_oracle(dims, hidden, cdim, B):
+@pytest.mark.parametrize("dims,hidden,cdim,B,layers", [([60, 45, 70], [40, 32], 5, 200, [128, 64, 32]),
+                                                        ([379, 379, 379], [110, 110], 29, 256, [128, 64, 32]),
+                                                        ([60, 45, 70], [300, 160], 5, 200, [128, 64, 32]),   # "-H 300 300 ..": trunk on the general-shape path
+                                                        ([60, 45, 70], [40, 32], 5, 200, [128, 64, 32, 16]),  # "-Layers 128 64 32 16"
+                                                        ([60, 45, 70], [40, 32], 5, 83, [100, 90, 64, 40, 24])])
+def test_classifier_head_config5_shape_vs_oracle(dims, hidden, cdim, B, layers):
     """The end-to-end model with the config-5 head (Z = 64, classifier [128, 64, 32]) at a small trunk with a ragged batch
     of 200 and at BASELINE config 5's full shape (3 x 379 ROI, H = [110, 110], c = 29, batch 256): logits, cross entropy,
     hinge, every gradient of the model (classifier weights / BatchNorm affine, and the trunk gradients that receive
     d CE / d z and the hinge row coefficients) against the oracle with the kernel's operand rounding; eval-mode
     predict() against the oracle with running statistics."""
-    Z, layers = 64, [128, 64, 32]
+    Z = 64
     torch.manual_seed(9)
     model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
                                         dropout_rate=0.0, num_classes=2)

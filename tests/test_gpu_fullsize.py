@@ -325,7 +325,7 @@ def test_deviation_pass_at_size_vs_oracle(D, N):
         assert bool((job.out_sqerr[0].storage_offset() == 0))
 
 
-@pytest.mark.parametrize("kind", ["regression", "endtoend"])
+@pytest.mark.parametrize("kind", ["regression", "endtoend", "endtoend-deep"])
 def test_head_models_one_launch_full_size_trajectory_vs_oracle(kind):
     """nm_train_steps_head at BASELINE sizes (3 x 379 ROI, H = [110, 110]; regression: Z = 10, two raw covariates;
     end-to-end = config 5: Z = 64, 29 covariates, classifier [128, 64, 32], dropout 0): three Adam steps inside ONE launch
@@ -336,7 +336,8 @@ def test_head_models_one_launch_full_size_trajectory_vs_oracle(kind):
     steps, B, lr = 3, 256, 1e-4
     dims, hidden = [379, 379, 379], [110, 110]
     Z, cdim = (10, 2) if kind == "regression" else (64, 29)
-    layers = [128, 64, 32]
+    # ("-Layers 128 64 32 16" of commands_list9_endtoend.sh:21, and a five-block stack: NM_MAX_CLS)
+    layers = [128, 64, 32] if kind != "endtoend-deep" else [128, 96, 64, 32, 16]
     g = torch.Generator().manual_seed(77)
     xes = [torch.randn(steps * B, d, generator=g) for d in dims]
     c = torch.rand(steps * B, cdim, generator=g)

@@ -58,15 +58,15 @@ def resources(asm_text: str):
 
 
 # Ceilings per kernel family (substring of the mangled name).  The persistent kernels must not spill vector registers;
-# the step / general-shape kernels must not touch scratch at all.  SGPR spills (v_writelane / v_readlane into a reserved
+# no kernel may touch scratch at all (the classifier head once kept a pointer table in private memory: 88 bytes).  SGPR spills (v_writelane / v_readlane into a reserved
 # VGPR, no memory traffic) are bounded at what the current source needs plus a margin, so that a change that makes the
 # scalar pressure worse is seen at build time (round 2 built 458 / 512 without anyone looking).
 LIMITS = {
     "nm_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 540},
     "nm_wide_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 300},
-    "nm_head_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 96, "sgpr_spill_count": 580},
+    "nm_head_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 580},
     "nm_reghead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 16},
-    "nm_clshead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 96, "sgpr_spill_count": 16},
+    "nm_clshead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 24},
 }
 
 
