@@ -86,6 +86,7 @@ class NmJob(C.Structure):
         ("cls_dropout", C.c_float), ("cls_margin", C.c_float), ("cls_w_ce", C.c_float), ("cls_w_contrast", C.c_float),
         ("labels", C.c_void_p), ("out_logits", C.c_void_p), ("dz_out", C.c_void_p),
         ("rowcoef_out", C.c_void_p * NM_MAX_MOD),
+        ("gpart", C.c_void_p), ("gpart_stride", C.c_int64), ("n_params", C.c_int64),
         ("mod", NmModality * NM_MAX_MOD),
     ]
 
@@ -125,6 +126,10 @@ def load():
     lib.nm_launch_split.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_launch_wide.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_split_errors.argtypes = [vp, i32, vp, i32, vp]
+    lib.nm_launch_rowsplit.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.nm_rowsplit_ok.argtypes = [C.POINTER(NmJob)]
+    lib.nm_sync_reset.argtypes = [vp, i32, vp]
+    lib.nm_trace_read_rs.argtypes = [C.POINTER(C.c_ulonglong), i32]
     lib.nm_combine_latent.argtypes = [vp, vp, i32, i64, i32, vp, i32, i32, i32, f32, vp, vp, vp]
     lib.nm_total_correlation.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
@@ -162,6 +167,7 @@ EXPORTED_SYMBOLS = [
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_wgtimes_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
     "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split", "nm_launch_wide", "nm_split_errors", "nm_combine_latent", "nm_total_correlation",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
+    "nm_launch_rowsplit", "nm_rowsplit_ok", "nm_sync_reset", "nm_trace_read_rs",
 ]
 
 

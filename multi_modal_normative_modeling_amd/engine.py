@@ -180,6 +180,8 @@ class Job:
         self._ws_tiles = 0
         self._version = 0                # bumped whenever the descriptor would change
         self._wsh = None                 # bf16 shadow images of the weights (nm_job_t.wsh)
+        self._gpart = None               # row-split launch: k slices of fp32 gradient partials (nm_job_t.gpart)
+        self._gpart_k = 0
         self.shadow_dirty = True         # params were written by the host: nm_sync_shadow before the next launch
         self._ensure_workspace(n_tiles_ws)
         # optional exports
@@ -217,6 +219,24 @@ class Job:
         self._ws = torch.zeros(self.ws_bytes * n_tiles, dtype=torch.uint8, device=self.device)
         self._ws_tiles = n_tiles
         self._version += 1
+
+    @property
+    def gpart_stride(self) -> int:
+        return (int(self.params.numel()) + 255) // 256 * 256
+
+    def _ensure_rowsplit(self, k: int):
+        """Buffers of a row-split launch with k slices per (model, modality): k workspace tiles, k gradient-partial slices."""
+        self._ensure_workspace(k)
+        if self._gpart is None or self._gpart_k < k:
+            self._gpart = torch.zeros(k * self.gpart_stride, dtype=torch.float32, device=self.device)
+            self._gpart_k = k
+            self._version += 1
+
+    def rowsplit_ok(self) -> bool:
+        """Can this model run row-split (nm_rowsplit_ok: plain cVAE / cVAE_multimodal-type models on the fused kernel)?"""
+        s = self.spec
+        return (not s.wide and s.kind in ("single", "multimodal") and len(self.kmods) == s.M and s.M <= _lib.NM_MAX_EXP
+                and self.tc_weight == 0.0)
 
     def set_fi(self, fi):
         """Regression target per table row (FI, ..._regression.py:86-87); padded with zeros to rows_alloc."""
@@ -344,6 +364,9 @@ class Job:
         j.loss_log = self.loss_log.data_ptr()
         j.workspace = self._ws.data_ptr()
         j.workspace_stride = self.ws_bytes
+        j.n_params = int(self.params.numel())
+        j.gpart = self._gpart.data_ptr() if self._gpart is not None else None
+        j.gpart_stride = self.gpart_stride
         j.wsh = self._wsh.data_ptr()
         j.out_mu = self.out_mu.data_ptr() if self.out_mu is not None else None
         j.out_logvar = self.out_logvar.data_ptr() if self.out_logvar is not None else None
@@ -538,13 +561,48 @@ class JobSet:
         fits = (len(self.jobs) + 7) // 8 * 8 * M <= cus
         return M if fits else 1
 
-    def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False, split: Optional[bool] = None):
-        """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam).  Small sets run every
-        model as M workgroups (split=None: automatically; results are bit-identical either way)."""
+    def rowsplit_k(self) -> int:
+        """Row slices per (model, modality) for a training launch (nm_launch_rowsplit): the largest k in {4, 2} for which
+        all ceil(jobs * M / 8) * 8 * k workgroups are resident at once, 1 if the set is too large for that or a model
+        needs the whole batch in one workgroup.  NMHIP_ROWSPLIT = 0 switches it off, 2 / 4 cap k."""
+        mode = os.environ.get("NMHIP_ROWSPLIT", "auto")
+        M = len(self.jobs[0].kmods)
+        if mode == "0" or self.wide or any(len(j.kmods) != M or not j.rowsplit_ok() for j in self.jobs):
+            return 1
+        if not hasattr(self, "_cus"):
+            self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        groups = (len(self.jobs) * M + 7) // 8 * 8
+        kmax = int(mode) if mode in ("2", "4") else 4
+        for k in (4, 2):
+            if k <= kmax and groups * k <= self._cus:
+                return k
+        return 1
+
+    def _launch_rowsplit(self, k: int, step0: int, n_steps: int, flags: int):
+        for j in self.jobs:
+            j._ensure_rowsplit(k)
+        ptr = self._upload(k)
+        _lib.check(self.lib.nm_launch_rowsplit(ptr, len(self.jobs), len(self.jobs[0].kmods), int(k), int(step0), int(n_steps),
+                                               int(flags), _stream_ptr(self.device)), "nm_launch_rowsplit")
+        self._split_pending = True
+
+    def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False, split: Optional[bool] = None,
+              rowsplit: Optional[int] = None):
+        """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam).  Small sets put several
+        workgroups behind a model: k row slices per (model, modality) (rowsplit=None: rowsplit_k(); results agree with the
+        one-workgroup launch to fp32 summation order), else one workgroup per modality (split=None: automatically;
+        bit-identical to the one-workgroup launch)."""
         step0 = self.jobs[0].step
         if any(j.step != step0 for j in self.jobs):
             raise ValueError("jobs of one set must be at the same step")
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | (_lib.NM_F_PROFILE if profile else 0)
+        k = (self.rowsplit_k() if split is None else 1) if rowsplit is None else int(rowsplit)
+        if k > 1 and not scalar_tr:
+            self._launch_rowsplit(k, step0, n_steps, flags)
+            for j in self.jobs:
+                j.step += n_steps
+                j.t += n_steps
+            return
         parts = self.split_parts() if split is None else (len(self.jobs[0].kmods) if split else 1)
         if parts > 1 and not scalar_tr:
             ptr = self._upload(1)
@@ -557,11 +615,14 @@ class JobSet:
             j.step += n_steps
             j.t += n_steps
 
-    def grads(self, step: Optional[int] = None, export: bool = True, scalar_tr: bool = False, split: bool = False):
+    def grads(self, step: Optional[int] = None, export: bool = True, scalar_tr: bool = False, split: bool = False,
+              rowsplit: int = 1):
         """forward + loss + backward for one step; gradients land in job.grads (no update)."""
         s = self.jobs[0].step if step is None else step
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | (_lib.NM_F_EXPORT if export else 0)
-        if split:
+        if rowsplit > 1:
+            self._launch_rowsplit(rowsplit, s, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS)
+        elif split:
             ptr = self._upload(1)
             _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), len(self.jobs[0].kmods), int(s), 1, int(flags),
                                                 _stream_ptr(self.device)), "nm_launch_split")

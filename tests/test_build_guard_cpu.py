@@ -38,7 +38,7 @@ def test_kernel_isa_has_no_spill_ahead_of_exec_restore_and_step_kernel_does_not_
     kernels 0 VGPR spills, 0 bytes of scratch and SGPR spills bounded (they were printed, not gated)."""
     m = _mod()
     assert m.main() == 0
-    for fam in ("nm_step_kernel", "nm_wide_step_kernel"):
+    for fam in ("nm_step_kernel", "nm_wide_step_kernel", "nm_rs_kernel"):
         assert m.LIMITS[fam]["vgpr_spill_count"] == 0 and m.LIMITS[fam]["private_segment_fixed_size"] == 0
         assert m.LIMITS[fam]["sgpr_spill_count"] <= 540
     for fam in ("nm_head_step_kernel", "nm_clshead_kernel", "nm_reghead_kernel"):

@@ -47,6 +47,7 @@ def _probe(M=1, L=2, Z=10, C_=29, H=(110, 110), D=379):
         j.mod[m].x_pitch = (D + 3) // 4 * 4
         j.mod[m].Cz = (C_ + 1 + 7) // 8 * 8
     j.n_rows, j.loss_cap, j.eps_cap = 256, 1, 1
+    j.n_params = 118479    # config A's parameter count
     j.wsh = 4096           # any non-null address: validation does not dereference it
     return j
 
@@ -70,6 +71,20 @@ def test_validate_job_limits(lib):
     bad = _probe()
     bad.wsh = None
     assert lib.nm_validate_job(C.byref(bad)) == -15
+    for n in (0, 1 << 30):                                      # 32-bit byte offsets into params / adam_m / adam_v
+        bad = _probe()
+        bad.n_params = n
+        assert lib.nm_validate_job(C.byref(bad)) == -21
+    # row-split launch: plain multimodal models with a partial-gradient buffer only
+    ok = _probe(M=3)
+    ok.w_off, ok.gpart, ok.gpart_stride = -1, 4096, 118528
+    assert lib.nm_rowsplit_ok(C.byref(ok)) == 0
+    for field, val in (("gpart", None), ("gpart_stride", 118479), ("tc_weight", 1e-4), ("w_off", 0), ("n_private", 2),
+                       ("out_kind", 1), ("M_enc", 2), ("reg_head", 1), ("wide", 1)):
+        bad = _probe(M=3)
+        bad.w_off, bad.gpart, bad.gpart_stride = -1, 4096, 118528
+        setattr(bad, field, val)
+        assert lib.nm_rowsplit_ok(C.byref(bad)) == -20, field
     bad = _probe()
     bad.mod[0].enc_w[0] = 8                                     # weight matrices start on a tile boundary
     assert lib.nm_validate_job(C.byref(bad)) == -10

@@ -5,7 +5,7 @@ lanes can be placed at the head of the branch's merge block, before `s_or_b64 ex
 execution mask -- lanes outside the branch then never store, and the later reload returns stale scratch.  (It
 showed up as an NLL off by exactly 0.5*|logvar_out| per row for one ROI column of one test shape.)
 
-The script compiles csrc/nmhip.hip to ISA and reports every basic block that touches scratch before its first
+The script compiles csrc/nmhip.hip and csrc/nm_rowsplit.hip to ISA and reports every basic block that touches scratch before its first
 EXEC restore.  Exit status 1 if any is found.  Fix at the source: keep divergent branches out of high-pressure
 regions (hoist descriptor loads out of per-lane selects, use selects / predicated stores instead of `if`)."""
 import re, subprocess, sys, tempfile
@@ -63,6 +63,7 @@ def resources(asm_text: str):
 # scalar pressure worse is seen at build time (round 2 built 458 / 512 without anyone looking).
 LIMITS = {
     "nm_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 540},
+    "nm_rs_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 480},
     "nm_wide_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 300},
     "nm_head_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 580},
     "nm_reghead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 16},
@@ -71,17 +72,23 @@ LIMITS = {
 
 
 def compile_isa() -> str:
-    src = ROOT / "multi_modal_normative_modeling_amd" / "csrc" / "nmhip.hip"
     with tempfile.TemporaryDirectory() as d:
-        out = Path(d) / "nmhip.s"
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-               f"-I{ROOT / 'include'}", str(src), "-o", str(out)]
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-        return out.read_text()
+        procs = []
+        for name in ("nmhip", "nm_rowsplit"):           # (both at once: ~80 s each)
+            src = ROOT / "multi_modal_normative_modeling_amd" / "csrc" / f"{name}.hip"
+            out = Path(d) / f"{name}.s"
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                   f"-I{ROOT / 'include'}", str(src), "-o", str(out)]
+            procs.append((out, cmd, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
+        for out, cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        return "\n".join(out.read_text() for out, _, _ in procs)
 
 
-def main():
-    text = compile_isa()
+def main(listings=()):
+    # ISA listings handed in (build() compiles them beside the objects), else the translation units are compiled here
+    text = "\n".join(Path(a).read_text() for a in listings) if listings else compile_isa()
     bad = scan(text)
     print(f"blocks with scratch traffic ahead of the EXEC restore: {len(bad)}")
     for label, ln, sc in bad:
@@ -101,4 +108,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(sys.argv[1:]))
