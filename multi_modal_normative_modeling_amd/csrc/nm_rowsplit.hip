@@ -22,167 +22,241 @@
 #include "nm_core.inc"
 
 // ---- Adam sweep over the summed partials ---------------------------------------------------------------------------
-// One weight-gradient pass G (the geometry run_step used for it): its 16 x 16 tiles are dealt round-robin over the
-// KS * 8 waves of the modality's KS slices, starting at global tile number `base` (the running tile count of the
-// passes before it, so that consecutive small passes keep all waves busy).  Per tile: p / m / v and the KS partials
-// (lane-linear 1-KiB tiles), g = ((g_0 + g_1) + g_2) + g_3, Adam, p / m / v back, the new weights as bf16 into the shadow
-// image (write-through: every slice's next forward reads it).  Returns the tile count of the pass.
-template <int KS>
-__device__ __forceinline__ int rs_sweep_pass(const Ctx& cc, const WgGeom& G, int base) {
+// All weight-gradient passes of a modality (the geometries run_step used) form ONE stream of 16 x 16 master tiles, dealt
+// round-robin over the KS * 8 waves of the modality's KS slices (the same tile always goes to the same wave of the same
+// workgroup: p / m / v of a tile are private to it).  Per tile: p / m / v and the KS partials (lane-linear 1-KiB tiles),
+// g = ((g_0 + g_1) + g_2) + g_3, Adam, p / m / v back, the new weights as bf16 into the shadow image (write-through: every
+// slice's next forward reads it).
+//
+// A wave keeps SW_DEPTH tiles in flight: the requests are hand-issued (asm, destination tied, always 3 + KS per tile) and
+// hand-waited with a counted vmcnt -- per pass a wave has only a tile or two, so a loop per pass with the compiler's
+// waits costs one exposed memory round trip per pass (the first version: 90 k cycles of a 345 k-cycle step).  The passes'
+// geometries sit in a small table in S (all of P / Q / S is dead during the sweep), built by one thread per pass.
+#ifndef NM_SW_DEPTH
+#define NM_SW_DEPTH 4
+#endif
+constexpr int SW_DEPTH = NM_SW_DEPTH;
+constexpr int SW_NV = 3;                 // vector elements per thread (biases, logvar_out, alpha: 2 D + ... per modality)
+struct SwRec { int w_off, KT, kt0, nkt; float rnkt; int sh_pitch; GAS char* sh; };     // 32 bytes
+// One vector parameter segment: elements [idx0, idx0 + n) of the master (a bias, a chunk of logvar_out, alpha), with an
+// optional fp32 copy inside a shadow image's vector piece; `off` = its first element in the concatenation of all segments
+// of the modality, which is dealt thread-linear over the KS slices: one memory round trip for all of them.
+struct SwVec { int idx0, n, off, pad; GAS float* copy; };                                 // 24 bytes
+// The sweep's tables of one (job, modality): built once per launch (rs_build_tables) into the slice's workspace tile
+// (WsLayout::rs_tab), copied into S at the start of every sweep (the step's phases use S in between).
+struct SwTab {
+  int npass, ntot, nseg, vtot;
+  int tbase[NM_RS_MAX_PASSES + 1];        // running tile count of the passes
+  int pad_[3];
+  SwRec rec[NM_RS_MAX_PASSES];
+  SwVec vec[NM_RS_MAX_VSEGS];
+};
+static_assert(sizeof(SwTab) % 16 == 0 && (int)sizeof(SwTab) <= STAGE_FLOATS * 4 && (int)sizeof(SwTab) <= WS_RS_TAB_BYTES, "sweep tables fit S and their workspace slot");
+
+// pass number -> geometry, in the order run_step issues the passes
+__device__ __forceinline__ WgGeom sw_geom(const nm_job_t* J, int m, int g) {
+  const nm_modality_t& md = J->mod[m];
+  const int L = J->L, nck = (md.D + OCH - 1) / OCH;
+  if (g < nck) return geom_out(J, md, g, nullptr);
+  g -= nck;
+  if (g < L) return geom_dec(J, md, L - 1 - g, nullptr);
+  g -= L;
+  if (g < 2) return geom_head(J, md, g, nullptr);
+  g -= 2;
+  if (g < L - 1) return geom_enc(J, md, L - 1 - g, nullptr);
+  g -= L - 1;
+  return geom_l0(J, md, g, nullptr);
+}
+// vector segment number -> segment: per output chunk its bias and its logvar_out columns, the decoder layers' biases, then
+// the encoder's (heads, hidden layers, first layer) and alpha
+__device__ __forceinline__ SwVec sw_vseg(const nm_job_t* J, int m, int s) {
+  const nm_modality_t& md = J->mod[m];
+  const int L = J->L, nck = (md.D + OCH - 1) / OCH;
+  if (s < 2 * nck) {
+    const int ch = s >> 1, d0 = ch * OCH, valid = min(OCH, md.D - d0);
+    GAS float* const vec = (GAS float*)((GAS char*)J->wsh + md.out_s + (int64_t)ch * OBLOB_BYTES + OIMG_BYTES);
+    if (s & 1) return SwVec{(int)md.logvar_out + d0, J->out_kind == 1 ? 0 : valid, 0, 0, vec + OCH};
+    return SwVec{(int)md.out_b + d0, valid, 0, 0, vec};
+  }
+  s -= 2 * nck;
+  WgGeom G;
+  if (s < L) G = geom_dec(J, md, s, nullptr);
+  else if (s < L + 2) G = geom_head(J, md, s - L, nullptr);
+  else if (s < 2 * L + 1) G = geom_enc(J, md, s - L - 1, nullptr);
+  else if (s == 2 * L + 1) G = geom_l0(J, md, 0, nullptr);
+  else return SwVec{(int)md.alpha, 1, 0, 0, nullptr};
+  return SwVec{(int)G.T.b_off, G.N, 0, 0, G.T.sh_b};
+}
+
+// Once per launch: the tables of modality m into S, from there into the workspace slot `gtab`.
+__device__ __forceinline__ void rs_build_tables(const Ctx& cc, int m, GAS char* gtab) {
   Ctx c = cc;
   relaunder(c);
   const nm_job_t* J = c.job;
-  const WgT& T = G.T;
-  const int KT = ktiles(G.K), kt0 = G.k_base >> 4;
-  const int nkt = min((G.ncols + 15) >> 4, KT - kt0);          // k tiles of this pass that exist in the master
-  const int ntn = (G.N + 15) >> 4;
-  const int ntiles = ntn * nkt;
+  const nm_modality_t& md = J->mod[m];
+  SwTab* const tab = reinterpret_cast<SwTab*>(c.stage);
+  const int L = J->L, Me = experts(J);
+  const int nck = (md.D + OCH - 1) / OCH, nch = (md.Kx + XCH - 1) / XCH;
+  const bool enc = m < Me;
+  const bool has_alpha = enc && md.alpha >= 0 && J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass);
+  const int npass = min(nck + L + (enc ? 2 + (L - 1) + nch : 0), NM_RS_MAX_PASSES);
+  const int nseg = min(2 * nck + L + (enc ? 2 + L : 0) + (has_alpha ? 1 : 0), NM_RS_MAX_VSEGS);
+  for (int g = c.tid; g < npass; g += WG) {
+    const WgGeom G = sw_geom(J, m, g);
+    const int KT = ktiles(G.K), kt0 = G.k_base >> 4;
+    const int nkt = min((G.ncols + 15) >> 4, KT - kt0);                      // k tiles of the pass that exist in the master
+    tab->rec[g] = SwRec{(int)G.T.w_off, KT, kt0, nkt, 1.0f / (float)nkt, G.T.sh_pitch, G.T.sh};
+    tab->tbase[g + 1] = ((G.N + 15) >> 4) * nkt;
+  }
+  for (int sI = c.tid; sI < nseg; sI += WG) tab->vec[sI] = sw_vseg(J, m, sI);   // (a decoder-only modality ends after its decoder layers)
+  lds_barrier();
+  if (c.tid == 0) {
+    int acc = 0;
+    tab->tbase[0] = 0;
+    for (int g = 0; g < npass; ++g) { acc += tab->tbase[g + 1]; tab->tbase[g + 1] = acc; }
+    int off = 0;
+    for (int sI = 0; sI < nseg; ++sI) { tab->vec[sI].off = off; off += tab->vec[sI].n; }
+    tab->npass = npass; tab->ntot = acc; tab->nseg = nseg; tab->vtot = off;
+  }
+  lds_barrier();
+  for (int i = c.tid; i < (int)sizeof(SwTab) / 16; i += WG)
+    *(GAS u32x4*)(gtab + i * 16) = reinterpret_cast<const u32x4*>(tab)[i];
+  handoff_barrier();
+}
+
+template <int KS>
+__device__ __forceinline__ void rs_sweep(const Ctx& cc, int m, const GAS char* gtab) {
+  Ctx c = cc;
+  relaunder(c);
+  const nm_job_t* J = c.job;
+  SwTab* const tab = reinterpret_cast<SwTab*>(c.stage);
+  lds_barrier();                                   // S is drained by whatever ran before
+  for (int i = c.tid; i < (int)sizeof(SwTab) / 16; i += WG)
+    reinterpret_cast<u32x4*>(tab)[i] = *(const GAS u32x4*)(gtab + i * 16);
+  lds_barrier();
+  const SwRec* const rec = tab->rec;
+  const int* const tbase = tab->tbase;
+  const int ntot = tab->ntot;
+  tr(c, 44);
   const bool do_adam = (c.flags & NM_F_ADAM) != 0, do_grads = (c.flags & NM_F_GRADS) != 0;
   const AdamK ak = adam_consts(c);
   gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
   const GAS float* const g0 = c.gpart - (int64_t)c.rsq * c.gp_stride;      // slice 0's partials
-  const int stride = KS * NWAVES, gw = c.rsq * NWAVES + c.wave;
+  const unsigned gstride_b = (unsigned)(c.gp_stride << 2);                  // (k * gpart_stride * 4 < 2^32: nm_rowsplit_ok)
+  const int stride = KS * NWAVES;
   const int prow = c.lane >> 2, pcol = (c.lane & 3) * 4;
-  int t = gw - base % stride;
-  t += t < 0 ? stride : 0;
-  // two tiles per iteration: both tiles' loads are issued before the first store
-  for (; t < ntiles; t += 2 * stride) {
-    const int t1 = t + stride;
-    const bool has1 = t1 < ntiles;
-    int64_t idx[2];
-    int nt[2], ktl[2];
+  const unsigned lane16 = (unsigned)c.lane << 4;
+  constexpr int L = 3 + KS;                                                  // vector-memory operations of one request
+  const int S_lb = (do_adam ? 4 : 0) + (do_grads ? 1 : 0);                   // stores of one finished tile
+
+  // ---- the vector segments first: up to SW_NV elements per thread, requested now, finished after the tile stream ----
+  // (vtot <= 2 * WG * SW_NV: nm_rowsplit_ok)
+  int64_t vidx[SW_NV];
+  GAS float* vcopy[SW_NV];
+  float vg[SW_NV][KS], vp[SW_NV], vm[SW_NV], vv[SW_NV];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tt = j ? (has1 ? t1 : t) : t;
-      nt[j] = tt / nkt;                                          // wave-uniform
-      ktl[j] = tt - nt[j] * nkt;
-      idx[j] = T.w_off + ((int64_t)(nt[j] * KT + kt0 + ktl[j]) << 8) + c.lane * 4;
+  for (int i = 0; i < SW_NV; ++i) {
+    const int e0 = (i * KS + c.rsq) * WG + c.tid;
+    vidx[i] = -1; vcopy[i] = nullptr; vp[i] = 0.f; vm[i] = 0.f; vv[i] = 0.f;
+#ifdef NM_RS_NO_VEC
+    if (false) {
+#else
+    if (e0 < tab->vtot) {
+#endif
+      int sgi = 0;
+      for (int sI = 1; sI < tab->nseg; ++sI) sgi += (e0 >= tab->vec[sI].off) ? 1 : 0;
+      const SwVec sg = tab->vec[sgi];
+      vidx[i] = sg.idx0 + (e0 - sg.off);
+      vcopy[i] = sg.copy ? sg.copy + (e0 - sg.off) : (GAS float*)nullptr;
     }
-    f32x4 gq[2][KS], p4[2], m4[2], v4[2];
+    const int64_t li = vidx[i] >= 0 ? vidx[i] : 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < KS; ++q) gq[j][q] = *(const GAS f32x4*)(g0 + (int64_t)q * c.gp_stride + idx[j]);
-      if (do_adam) {
-        p4[j] = *(const GAS f32x4*)(Pp + idx[j]);
-        m4[j] = __builtin_nontemporal_load((const GAS f32x4*)(Mp + idx[j]));
-        v4[j] = __builtin_nontemporal_load((const GAS f32x4*)(Vp + idx[j]));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !has1) break;                                // wave-uniform
-      f32x4 g = gq[j][0];
-#pragma unroll
-      for (int q = 1; q < KS; ++q) g += gq[j][q];                // slice order
-      if (do_grads) *(GAS f32x4*)(asg(J->grads) + idx[j]) = g;
-      if (do_adam) {
-        f32x4 pn = p4[j], mn = m4[j], vn = v4[j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { float pp = pn[i], mm = mn[i], v2 = vn[i]; adam1(ak, g[i], pp, mm, v2); pn[i] = pp; mn[i] = mm; vn[i] = v2; }
-        *(GAS f32x4*)(Pp + idx[j]) = pn;
-        __builtin_nontemporal_store(mn, (GAS f32x4*)(Mp + idx[j]));
-        __builtin_nontemporal_store(vn, (GAS f32x4*)(Vp + idx[j]));
-        if (T.sh) {
-          bf16x4 pk;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pn[i];
-          st8_wt(T.sh + (int64_t)(nt[j] * 16 + prow) * T.sh_pitch + (ktl[j] * 16 + pcol) * 2, pk);
-        }
-      }
-    }
+    for (int q = 0; q < KS; ++q) vg[i][q] = g0[(int64_t)q * c.gp_stride + li];
+    if (do_adam) { vp[i] = Pp[li]; vm[i] = Mp[li]; vv[i] = Vp[li]; }
   }
-  return ntiles;
-}
 
-// One vector parameter segment: elements [idx0, idx0 + n) of the master (a bias, a chunk of logvar_out, alpha), with an
-// optional fp32 copy inside a shadow image's vector piece.  All segments of a modality form one flat element range that
-// is dealt thread-linear over the KS slices: one memory round trip for all of them.
-struct VSeg { int64_t idx0; int n; GAS float* copy; };
-
-template <int KS>
-__device__ __forceinline__ void rs_sweep_vectors(const Ctx& cc, int m) {
-  Ctx c = cc;
-  relaunder(c);
-  const nm_job_t* J = c.job;
-  const nm_modality_t& md = J->mod[m];
-  const int L = J->L, Me = experts(J);
-  const int nck = (md.D + OCH - 1) / OCH;
-  const bool sigm = J->out_kind == 1;
-  const bool has_alpha = m < Me && md.alpha >= 0 && J->combine == NM_COMBINE_GPOE && !(Me == 1 && J->single_bypass);
-  const bool do_adam = (c.flags & NM_F_ADAM) != 0, do_grads = (c.flags & NM_F_GRADS) != 0;
-  // segment s (wave-uniform): 2 per output chunk (bias, logvar_out), decoder layers, then the encoder's
-  const int n_out = 2 * nck, n_dec = L, n_enc = m < Me ? 2 + L : 0;          // heads (2), hidden layers (L - 1), first layer (1)
-  const int nseg = n_out + n_dec + n_enc + (has_alpha ? 1 : 0);
-  auto seg = [&](int s) -> VSeg {
-    if (s < n_out) {
-      const int ch = s >> 1, d0 = ch * OCH, valid = min(OCH, md.D - d0);
-      GAS float* const vec = (GAS float*)((GAS char*)J->wsh + md.out_s + (int64_t)ch * OBLOB_BYTES + OIMG_BYTES);
-      if (s & 1) return VSeg{md.logvar_out + d0, sigm ? 0 : valid, vec + OCH};
-      return VSeg{md.out_b + d0, valid, vec};
-    }
-    s -= n_out;
-    if (s < n_dec) { const WgGeom G = geom_dec(J, md, s, nullptr); return VSeg{G.T.b_off, G.N, G.T.sh_b}; }
-    s -= n_dec;
-    if (s < 2 && n_enc) { const WgGeom G = geom_head(J, md, s, nullptr); return VSeg{G.T.b_off, G.N, G.T.sh_b}; }
-    s -= 2;
-    if (s < L - 1 && n_enc) { const WgGeom G = geom_enc(J, md, s + 1, nullptr); return VSeg{G.T.b_off, G.N, G.T.sh_b}; }
-    s -= L - 1;
-    if (s == 0 && n_enc) { const WgGeom G = geom_l0(J, md, 0, nullptr); return VSeg{G.T.b_off, G.N, G.T.sh_b}; }
-    return VSeg{md.alpha, 1, nullptr};
+  struct Slot { f32x4 p, m, v, g[KS]; unsigned boff; GAS char* shp; };
+  Slot sl[SW_DEPTH];
+#pragma unroll
+  for (int s = 0; s < SW_DEPTH; ++s) {
+    asm volatile("" : "=v"(sl[s].p), "=v"(sl[s].m), "=v"(sl[s].v));
+#pragma unroll
+    for (int q = 0; q < KS; ++q) asm volatile("" : "=v"(sl[s].g[q]));
+  }
+  int gi = 0;                                      // pass cursor of the NEXT tile to request (tiles come in ascending order)
+  int Tn = c.rsq * NWAVES + c.wave;                // next tile of this wave
+  auto issue = [&](Slot& z) {
+    while (Tn >= tbase[gi + 1]) ++gi;
+    const SwRec r = rec[gi];
+    const int lt = Tn - tbase[gi];
+    const int nt = idiv(lt, r.nkt, r.rnkt), ktl = lt - nt * r.nkt;
+    z.boff = ((unsigned)(r.w_off + ((nt * r.KT + r.kt0 + ktl) << 8)) << 2) + lane16;
+    z.shp = r.sh + (int64_t)(nt * 16 + prow) * r.sh_pitch + (ktl * 16 + pcol) * 2;
+    NM_GLOAD16(z.p, z.boff, Pp); NM_GLOAD16_NT(z.m, z.boff, Mp); NM_GLOAD16_NT(z.v, z.boff, Vp);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) { const unsigned o = z.boff + (unsigned)q * gstride_b; NM_GLOAD16(z.g[q], o, g0); }
+    Tn += stride;
   };
-  // this thread's element of the concatenation: walk the segments (wave-uniform loop, per-lane selects)
-  const int e = c.rsq * WG + c.tid;                  // flat element index handled by this thread, then + KS * WG
-  const GAS float* const g0 = c.gpart - (int64_t)c.rsq * c.gp_stride;
-  gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
-  const AdamK ak = adam_consts(c);
-  int total = 0;
-  for (int s = 0; s < nseg; ++s) total += seg(s).n;
-  for (int e0 = e; e0 - c.tid - c.rsq * WG < total; e0 += KS * WG) {      // (wave-uniform trip count)
-    int64_t idx = -1;
-    GAS float* copy = nullptr;
-    int off = 0;
-    for (int s = 0; s < nseg; ++s) {
-      const VSeg sg = seg(s);
-      const bool in = e0 >= off && e0 < off + sg.n;
-      idx = in ? sg.idx0 + (e0 - off) : idx;
-      copy = in ? (sg.copy ? sg.copy + (e0 - off) : (GAS float*)nullptr) : copy;
-      off += sg.n;
-    }
-    if (idx >= 0) {
-      float g = g0[idx];
+  auto finish = [&](Slot& z) {
+    asm volatile("" : "+v"(z.p), "+v"(z.m), "+v"(z.v));
 #pragma unroll
-      for (int q = 1; q < KS; ++q) g += g0[(int64_t)q * c.gp_stride + idx];
-      if (do_grads) asg(J->grads)[idx] = g;
-      if (do_adam) {
-        float p = Pp[idx], mm = Mp[idx], v = Vp[idx];
-        adam1(ak, g, p, mm, v);
-        st4_wt(Pp + idx, p);                         // (alpha is read by every part; the others only through `copy`)
-        Mp[idx] = mm; Vp[idx] = v;
-        if (copy) st4_wt(copy, p);
+    for (int q = 0; q < KS; ++q) asm volatile("" : "+v"(z.g[q]));
+    f32x4 g = z.g[0];
+#pragma unroll
+    for (int q = 1; q < KS; ++q) g += z.g[q];      // slice order
+    const int64_t idx = (int64_t)(z.boff >> 2);
+    if (do_grads) *(GAS f32x4*)(asg(J->grads) + idx) = g;
+    if (do_adam) {
+      f32x4 pn = z.p, mn = z.m, vn = z.v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float pp = pn[i], mm = mn[i], v2 = vn[i]; adam1(ak, g[i], pp, mm, v2); pn[i] = pp; mn[i] = mm; vn[i] = v2; }
+      *(GAS f32x4*)(Pp + idx) = pn;
+      __builtin_nontemporal_store(mn, (GAS f32x4*)(Mp + idx));
+      __builtin_nontemporal_store(vn, (GAS f32x4*)(Vp + idx));
+      bf16x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pn[i];
+      st8_g(c, z.shp, pk);
+    }
+  };
+  bool valid[SW_DEPTH];
+  int inflight = 0, done = 0;
+#pragma unroll
+  for (int s = 0; s < SW_DEPTH; ++s) {
+    valid[s] = Tn < ntot;
+    if (valid[s]) { issue(sl[s]); ++inflight; }
+  }
+  while (inflight > 0) {
+#pragma unroll
+    for (int s = 0; s < SW_DEPTH; ++s) {
+      if (valid[s]) {                                // wave-uniform
+        // younger than this tile's request: the requests of the tiles behind it, the stores of the tiles finished since
+        wait_vm_le((inflight - 1) * L + min(done, SW_DEPTH - 1) * S_lb);
+        finish(sl[s]);
+        ++done;
+        valid[s] = Tn < ntot;
+        if (valid[s]) issue(sl[s]); else --inflight;
       }
     }
   }
-}
-
-// All weight-gradient passes of modality m, in the order run_step issued them.
-template <int KS>
-__device__ __forceinline__ void rs_sweep(const Ctx& c, int m) {
-  const nm_job_t* J = c.job;
-  const nm_modality_t& md = J->mod[m];
-  const int L = J->L, Me = experts(J);
-  const int nck = (md.D + OCH - 1) / OCH;
-  int base = 0;
-  for (int ch = 0; ch < nck; ++ch) base += rs_sweep_pass<KS>(c, geom_out(J, md, ch, nullptr), base);
-  for (int d = L - 1; d >= 0; --d) base += rs_sweep_pass<KS>(c, geom_dec(J, md, d, nullptr), base);
-  if (m < Me) {
-    base += rs_sweep_pass<KS>(c, geom_head(J, md, 0, nullptr), base);
-    base += rs_sweep_pass<KS>(c, geom_head(J, md, 1, nullptr), base);
-    for (int e = L - 1; e >= 1; --e) base += rs_sweep_pass<KS>(c, geom_enc(J, md, e, nullptr), base);
-    const int nch = (md.Kx + XCH - 1) / XCH;
-    for (int kc = 0; kc < nch; ++kc) base += rs_sweep_pass<KS>(c, geom_l0(J, md, kc, nullptr), base);
+  tr(c, 45);
+  // ---- the vector elements of this thread (their loads were the first of the sweep) ----
+#pragma unroll
+  for (int i = 0; i < SW_NV; ++i) {
+    if (vidx[i] >= 0) {
+      float g = vg[i][0];
+#pragma unroll
+      for (int q = 1; q < KS; ++q) g += vg[i][q];
+      if (do_grads) asg(J->grads)[vidx[i]] = g;
+      if (do_adam) {
+        float pp = vp[i], mm = vm[i], v2 = vv[i];
+        adam1(ak, g, pp, mm, v2);
+        st4_wt(Pp + vidx[i], pp);                  // (alpha is read by every part; the others only through `copy`)
+        Mp[vidx[i]] = mm; Vp[vidx[i]] = v2;
+        if (vcopy[i]) st4_g(c, vcopy[i], pp);
+      }
+    }
   }
-  rs_sweep_vectors<KS>(c, m);
 }
 
 // ---- kernel ----------------------------------------------------------------------------------------------------------
@@ -191,7 +265,7 @@ __device__ __forceinline__ void rs_sweep(const Ctx& c, int m) {
 // the hand-off protocol): workgroup b = ((slot * KS + q) << 3) + xcd runs slice q of group slot * 8 + xcd = job * M + m.
 template <int KS>
 __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ jobs, int step0, int n_steps, int flags,
-                                                   int n_jobs, int M) {
+                                                   int n_jobs, int M, int spread_us) {
   constexpr int RTV = 8 / KS;
   NM_GEOM(RTV);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -211,7 +285,7 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
   relaunder(c);
   c.flags = flags;
   c.t_last = 0;
-  c.rsk = KS; c.rsq = q; c.rloc0 = q * ROWS; c.xwg = 1;
+  c.rsk = KS; c.rsq = q; c.rloc0 = q * ROWS; c.xwg = 1; c.gwt = 1;
   c.ws0 = (GAS char*)J->workspace;
   c.ws = c.ws0 + (int64_t)q * J->workspace_stride;
   c.gp_stride = J->gpart_stride;
@@ -219,10 +293,49 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   const WsLayout wl = ws_layout(J->M, J->L, J->Z);
+  GAS char* const gtab = c.ws + wl.rs_tab + (int64_t)part * WS_RS_TAB_BYTES;
+  rs_build_tables(c, part, gtab);
+#ifdef NM_RS_DEBUG_TABLES
+  {   // diagnostic build: dump the table header of workgroup (job 0, part 0, slice 0) into the loss log and leave
+    if (blockIdx.x == 0 && c.tid == 0 && J->loss_log) {
+      const GAS int* t = (const GAS int*)gtab;
+      gf32 row = asg(J->loss_log);
+      for (int i = 0; i < 16; ++i) row[i] = (float)t[i];
+      const GAS int* v = (const GAS int*)(gtab + 544 + NM_RS_MAX_PASSES * 32);
+      for (int i = 0; i < 16; ++i) row[16 + i] = (float)v[i];
+    }
+    return;
+  }
+#endif
   GAS unsigned* const sync0 = (GAS unsigned*)(c.ws0 + wl.sync);
   GAS unsigned* const sync_c = sync0 + WS_SYNC_C_WORD;
   GAS unsigned* const sync_d = sync0 + WS_SYNC_D_WORD + part;
   GAS unsigned* const sync_err = sync0 + WS_SYNC_ERR_WORD;
+  // Where do the KS workgroups of this group run?  Each publishes its XCD (XCC_ID, bits 3:0 of hardware register 20), the
+  // group meets once (arrival 1 of the D counter), and only if all KS ids agree -- they share one L2, which is then their
+  // coherence point -- the group's internal payload (gradient partials, shadow images) is stored plain and served from
+  // that L2 instead of being written through to memory and fetched back at the cross-XCD rate.  A placement that differs
+  // from the expected one (workgroups b and b + 8 on one XCD) costs speed, never correctness.
+  {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;
+    GAS unsigned* const my = (GAS unsigned*)(c.ws + wl.sync) + WS_SYNC_XCC_WORD + part;
+    if (c.tid == 0) __hip_atomic_store(my, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!split_handoff(c, sync_d, sync_err, (unsigned)KS)) return;
+    bool same = true;
+    for (int qq = 0; qq < KS; ++qq) {
+      const unsigned o = __hip_atomic_load((GAS unsigned*)(c.ws0 + (int64_t)qq * J->workspace_stride + wl.sync) + WS_SYNC_XCC_WORD + part,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      same = same && o == xcc + 1u;
+    }
+    c.gwt = (same && !(flags & NM_F_PROFILE)) ? 0 : 1;        // (NM_F_PROFILE here: force the write-through path, for A/B runs)
+  }
+  // start offsets: the models of a full chip otherwise reach their Adam sweeps -- the step's burst of memory traffic --
+  // together; job j starts j / n_jobs of spread_us late (constant-rate counter, as nm_step_kernel's dephase)
+  if (spread_us > 0 && n_jobs > 1) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ticks = 100ull * (unsigned long long)min(spread_us, 20000) * (unsigned long long)job_idx / (unsigned long long)n_jobs;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+  }
   const int nb = (J->n_rows + TROWS - 1) / TROWS;
   for (int s = step0; s < step0 + n_steps; ++s) {
     const int b = s % nb;
@@ -260,12 +373,13 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
       row[NM_LOSS_KL] = J->kl_weight * kl;
       row[NM_LOSS_LL] = ll_sum;
       row[NM_LOSS_TC] = 0.f;
+      row[15] = (float)c.gwt;                                   // (diagnostic: 0 = the group's payload stayed in one XCD's L2)
       row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
     }
-    rs_sweep<KS>(c, part);
+    rs_sweep<KS>(c, part, gtab);
     tr(c, 42);
     // D: the modality's new shadow images / vector pieces are complete (the next forward of every slice reads them)
-    if (!split_handoff(c, sync_d, sync_err, (unsigned)(c.lstep + 1) * (unsigned)KS)) break;
+    if (!split_handoff(c, sync_d, sync_err, (unsigned)(c.lstep + 2) * (unsigned)KS)) break;    // (arrival 1: the placement check)
     tr(c, 43);
   }
   if ((flags & 64) && blockIdx.x < 512 && c.tid == 0) nm_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
@@ -278,7 +392,8 @@ extern "C" {
 /* Row-split launch (include/nmhip.h): n_jobs models of M modalities each, k in {2, 4} row slices per (model, modality).
  * Every job needs k workspace tiles and gpart / gpart_stride; -16: the launch would not be resident at once;
  * -20: a job of the launch cannot run row-split (see nm_rowsplit_ok). */
-int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int step0, int n_steps, int flags, void* stream) {
+int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int step0, int n_steps, int flags, int spread_us,
+                       void* stream) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1 || n_steps < 1 || step0 < 0 || M < 1 || M > NM_MAX_EXP || (k != 2 && k != 4)) return -8;
   if (!(flags & NM_F_BACKWARD) || !(flags & (NM_F_ADAM | NM_F_GRADS))) return -8;
@@ -291,16 +406,17 @@ int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int s
   if (wgs > cus) return -16;            // the workgroups of a model wait for each other: all must be resident
   hipStream_t st = (hipStream_t)stream;
   nm_sync_reset(jobs_dev, n_jobs, stream);
-  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_TRACE | NM_F_FAULT_INJECT);
+  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_TRACE | NM_F_FAULT_INJECT | NM_F_PROFILE);
+  if (spread_us < 0 || n_steps < 16) spread_us = 0;          // (an offset is pure cost at the end of a short launch)
   hipError_t e;
   if (k == 2) {
     e = hipFuncSetAttribute((const void*)nm_rs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nm_rs_kernel<2>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M);
+    hipLaunchKernelGGL(nm_rs_kernel<2>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M, spread_us);
   } else {
     e = hipFuncSetAttribute((const void*)nm_rs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nm_rs_kernel<4>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M);
+    hipLaunchKernelGGL(nm_rs_kernel<4>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M, spread_us);
   }
   return (int)hipGetLastError();
 }

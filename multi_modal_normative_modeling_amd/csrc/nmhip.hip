@@ -1106,7 +1106,15 @@ int nm_rowsplit_ok(const nm_job_t* j) {
   if (j->w_off >= 0 || j->tc_weight != 0.f || j->n_private != 0 || j->out_kind != 0) return -20;
   if (j->M_enc != 0 && j->M_enc != j->M) return -20;
   if (j->M > NM_MAX_EXP) return -20;
-  if (!j->gpart || j->gpart_stride < j->n_params || (j->gpart_stride & 255)) return -20;
+  for (int m = 0; m < j->M; ++m) {                 // the sweep's tables (nm_rowsplit.hip): passes, vector segments and elements
+    const int nck = (j->mod[m].D + OCH - 1) / OCH, nch = (j->mod[m].Kx + XCH - 1) / XCH;
+    if (nck + 2 * j->L + 1 + nch > NM_RS_MAX_PASSES || 2 * nck + 2 * j->L + 3 > NM_RS_MAX_VSEGS) return -20;
+    int64_t vtot = 2 * (int64_t)j->mod[m].D + 2 * j->Z + 1;
+    for (int i = 0; i < j->L; ++i) vtot += 2 * j->H[i];
+    if (vtot > 2 * WG * 3) return -20;              // three vector elements per thread at k = 2 (nm_rowsplit.hip: SW_NV)
+  }
+  // (the sweep addresses slice q's partials at a 32-bit byte offset q * gpart_stride * 4 from slice 0's, q < 4)
+  if (!j->gpart || j->gpart_stride < j->n_params || (j->gpart_stride & 255) || j->gpart_stride >= ((int64_t)1 << 28)) return -20;
   return 0;
 }
 

@@ -582,8 +582,13 @@ class JobSet:
         for j in self.jobs:
             j._ensure_rowsplit(k)
         ptr = self._upload(k)
+        # start offsets over ~one step's time once the launch fills a good part of the chip (measured: 0.37 ns per
+        # parameter and step for one model at k = 4); NMHIP_RS_SPREAD scales it, 0 switches it off
+        wgs = len(self.jobs) * len(self.jobs[0].kmods) * k
+        scale = float(os.environ.get("NMHIP_RS_SPREAD", "1"))
+        spread = int(self.jobs[0].layout.n_params * 0.37e-3 * (4 / k) * scale) if wgs >= 96 else 0
         _lib.check(self.lib.nm_launch_rowsplit(ptr, len(self.jobs), len(self.jobs[0].kmods), int(k), int(step0), int(n_steps),
-                                               int(flags), _stream_ptr(self.device)), "nm_launch_rowsplit")
+                                               int(flags), spread, _stream_ptr(self.device)), "nm_launch_rowsplit")
         self._split_pending = True
 
     def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False, split: Optional[bool] = None,

@@ -192,7 +192,7 @@ def test_rowsplit_many_models_pick_and_refusal():
         j._ensure_rowsplit(2)
     ptr = big._upload(2)
     st = torch.cuda.current_stream().cuda_stream
-    assert _lib.load().nm_launch_rowsplit(ptr, 96, 3, 2, 0, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM, st) == -16
+    assert _lib.load().nm_launch_rowsplit(ptr, 96, 3, 2, 0, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM, 0, st) == -16
 
 
 def test_rowsplit_full_size_se_model_vs_oracle():
