@@ -38,7 +38,7 @@ def kernel_src_sha16() -> str:
     """Identity of the kernel source the loaded library was built from (bench <-> PMC record match)."""
     h = hashlib.sha256()
     csrc = ROOT / "multi_modal_normative_modeling_amd" / "csrc"
-    for p in (csrc / "nmhip.hip", csrc / "nm_wide.inc", ROOT / "include" / "nmhip.h"):
+    for p in (csrc / "nm_core.inc", csrc / "nmhip.hip", csrc / "nm_rowsplit.hip", csrc / "nm_wide.inc", ROOT / "include" / "nmhip.h"):
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
 
@@ -92,6 +92,78 @@ def device_record(torch, nm, js, dev, trace=True):
     return rec
 
 
+def strong_scaling(args, torch, nm, prep, sweep, workload, cohort, dev, dist, rank, world, log):
+    """--scaling strong: the reference's grid (5 folds x {SM-T1w, SM-T2w, SM-fMRI, UCA-gPoE}: SURVEY 8(e), commands_list_deviation.sh
+    :13-23) dealt over the ranks exactly as the sweep entry deals it (sweep.assign); every rank trains ITS cells -- grouped by
+    shape, each group one launch form picked by JobSet.train (row slices per modality for sets this small) -- round-robin for a
+    fixed wall-clock window.  value = steps of all cells of all ranks per second; the per-rank shares say how the 20 cells fell."""
+    procs = ["SM-T1w_sMRI", "SM-T2w_sMRI", "SM-fMRI", "UCA-gPoE"]
+    n_folds = 5
+    replicas = max(1, -(-args.cells // (n_folds * len(procs))))
+    cells = sweep.plan_cells(procs, n_folds, replicas, cohort.resource)[: args.cells]
+    mine = sweep.assign(cells, rank, world)
+    total_cost = sum(c.cost for c in cells)
+    folds = prep.kfold_indices(len(cohort.iid), n_folds, 42)
+    tables, groups = {}, {}
+    for c in mine:
+        mods, combine = workload.procedure_modalities(c.procedure, cohort.resource)
+        key = (c.fold, tuple(mods))
+        if key not in tables:
+            xs, cc = prep.fold_train_tables(cohort, mods, folds[c.fold][0])
+            tables[key] = [nm.Table(x, cc, dev) for x in xs]
+        spec = nm.ModelSpec([t.D for t in tables[key]], list(workload.HIDDEN), workload.LATENT, workload.C_DIM)
+        job = nm.Job(spec, tables[key], combine=combine, seed=1000 * c.fold + c.job_id, init_seed=42 + c.job_id, loss_cap=64)
+        groups.setdefault(tuple(spec.input_dims), []).append(job)
+    sets = [nm.JobSet(v) for v in groups.values()]
+    log(f"strong scaling: rank {rank} holds {len(mine)} of {len(cells)} cells in {len(sets)} shape group(s)")
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    spl = 32
+    for js in sets:                                   # warm-up: one launch per group
+        js.train(spl)
+    barrier()
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < args.window_s and sets:
+        for js in sets:
+            js.train(spl)
+            steps += spl * len(js.jobs)
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    for js in sets:
+        js.assert_finite()
+    barrier()
+    mine_rec = torch.tensor([float(rank), float(len(mine)), sum(c.cost for c in mine) / total_cost, float(steps), elapsed],
+                            dtype=torch.float64)
+    if dist is not None:
+        tdev = dev if args.backend == "nccl" else torch.device("cpu")
+        bufs = [torch.empty(5, dtype=torch.float64, device=tdev) for _ in range(world)]
+        dist.all_gather(bufs, mine_rec.to(tdev))
+        recs = [b.cpu().tolist() for b in bufs]
+    else:
+        recs = [mine_rec.tolist()]
+    if rank == 0:
+        wall = max(r[4] for r in recs)
+        total = sum(r[3] for r in recs)
+        out = {"metric": "cVAE training-steps/sec (batch 256, 379-ROI x 3-modality)", "value": round(total / wall, 2), "unit": "steps/s",
+               "n_gpus": world, "steps": int(total), "warmup": spl, "ms_per_step": round(wall / max(total, 1) * 1e3, 6),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"the reference's grid: {n_folds} folds x {procs} = {len(cells)} cells (SM: 379 ROI; UCA: 3 x 379 + 1137), "
+                                      f"batch 256, dealt by sweep.assign over {world} rank(s), {args.window_s} s window per rank",
+                          "cells": len(cells), "window_s": args.window_s, "steps_per_launch": spl, "parallelism": f"grid-sharded x{world}"},
+               "ranks": [{"rank": int(r[0]), "cells": int(r[1]), "cost_share": round(r[2], 4), "steps": int(r[3]),
+                          "elapsed_s": round(r[4], 4)} for r in recs],
+               "roofline": None, "cpu_baseline": None,
+               "note": "value = steps of every cell on every rank / the longest rank's window; a step of a UCA cell costs ~5x a "
+                       "single-modality cell's, so steps/s here is not comparable with the weak form's SE-model steps/s"}
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +189,16 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(affinity, 16))")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the\n                    multi-rank path on a one-GPU box together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's form): every rank trains its own --jobs models.  strong: the reference's "
+                         "own grid -- 5 folds x 4 procedures = --cells models (SURVEY 8(e)) -- dealt over the ranks by sweep.assign "
+                         "(descending cost, round-robin); every rank trains its cells for --window-s seconds; value = grid "
+                         "steps/s over all ranks")
+    ap.add_argument("--cells", type=int, default=20, help="--scaling strong: models of the grid (folds x procedures x replicas)")
+    ap.add_argument("--window-s", type=float, default=2.0, help="--scaling strong: wall-clock window every rank trains for")
+    ap.add_argument("--cpu-all-shapes", action="store_true",
+                    help="cpu_baseline also for the other BASELINE shapes (config 2, early fusion, UCA, config 5 trunk): "
+                         "a few seconds each, off by default so that the driver's form stays short")
     args = ap.parse_args()
 
     T0 = time.perf_counter()
@@ -133,6 +215,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.share_device:
         local_rank = 0
+        # several processes on ONE GPU: launches whose workgroups wait for each other (one workgroup per modality, row
+        # slices) need all of them resident at once -- two such launches from two processes can each hold half the CUs and
+        # time out on each other.  The rehearsal therefore runs every model as one workgroup.
+        os.environ["NMHIP_ROWSPLIT"] = "0"
+        os.environ["NMHIP_SPLIT"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -151,6 +238,11 @@ def main():
     # ---- workload: resident in HBM before timing ----
     cohort = prep.synthetic_cohort(n=args.subjects, d=379)
     log("synthetic cohort ready")
+    if args.scaling == "strong":
+        strong_scaling(args, torch, nm, prep, sweep, workload, cohort, dev, dist, rank, world, log)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     jobs = workload.build_sweep_jobs(cohort, args.procedure, 5, args.jobs, dev, seed0=rank * args.jobs,
                                      xcd_affinity={"none": False, "rank": "rank"}[args.placement])
     log(f"{len(jobs)} jobs resident on {dev}")
@@ -259,7 +351,8 @@ def main():
         out["device"] = device_record(torch, nm, js, dev, trace=not args.lean)
 
     # ---- small sweeps: the metric's literal shape (5 folds) and the reference's real grid (20 cells), one model alone ----
-    # (own short legs OUTSIDE the timed region above; the models run as one workgroup per modality: nm_launch_split)
+    # (own short legs OUTSIDE the timed region above; JobSet.train puts k row slices per modality behind every model:
+    #  nm_launch_rowsplit, k from the set size)
     if world == 1 and args.small_sweep and not args.lean and args.procedure == "SE-gPoE":
         small = {}
         pool = workload.build_sweep_jobs(cohort, args.procedure, 5, 26, dev, seed0=10_000)
@@ -277,8 +370,10 @@ def main():
             if name == "single_model":
                 small["single_model_us_per_step"] = round(best / 128 * 1e6, 2)
             else:
+                k = sj.rowsplit_k()
                 small[name] = {"steps_per_s": round(n * 128 / best, 1), "us_per_sweep_step": round(best / 128 * 1e6, 2),
-                               "workgroups": n * sj.split_parts()}
+                               "workgroups": n * len(sj.jobs[0].kmods) * k if k > 1 else n * sj.split_parts(),
+                               "row_slices_per_modality": k}
         small["note"] = "5 folds x 1 model = the metric's literal shape; 20 = 5 folds x 4 procedures; 128-step launches, best of 3"
         out["small_sweep"] = small
         log(f"small sweeps: {small}")
@@ -321,6 +416,22 @@ def main():
                                "kind": "port",
                                "sample": f"{n} train steps of ONE {args.procedure} model (same tables, batch 256) "
                                          f"in {n / sps:.1f} s, eager PyTorch CPU fp32 (oracle/cpu_baseline.py)"}
+        if args.cpu_all_shapes:
+            # the other BASELINE shapes, a few seconds each (seeded random tables of the shape: the rate does not depend on
+            # the values); one model per shape, the same stepper
+            others = {}
+            gen = torch.Generator().manual_seed(7)
+            for name, dims, Z in (("config2_SM_379", [379], 10), ("config4_early_fusion_1137", [1137], 10),
+                                  ("config4_UCA_3x379_1137", [379, 379, 379, 1137], 10), ("config5_trunk_3x379_Z64", [379, 379, 379], 64)):
+                rs2 = R.Spec(dims, list(spec.hidden), Z, spec.c_dim)
+                P2 = nm.ParamLayout(nm.ModelSpec(dims, list(spec.hidden), Z, spec.c_dim)).init_reference_rule(42)
+                st2 = CpuStepper(rs2, P2, "gpoe" if len(dims) > 1 else "poe")
+                cc = torch.zeros(256, spec.c_dim)
+                cc[torch.arange(256), torch.randint(0, spec.c_dim - 2, (256,), generator=gen)] = 1
+                bt = [([torch.randn(256, d, generator=gen) for d in dims], [cc.long()] * len(dims))]
+                sps2, n2 = time_cpu_steps(st2, bt, budget_s=min(4.0, args.cpu_budget))
+                others[name] = {"value": round(sps2, 2), "unit": "steps/s", "steps": n2}
+            out["cpu_baseline"]["other_shapes"] = others
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -249,7 +249,13 @@ class _Base(nn.Module):
             j.step = 0
             j.touch()
         if (flags & _lib.NM_F_BACKWARD) and nt == 1 and self.spec.kind == "multimodal" and self._js.split_parts() > 1:
-            self._js._launch_split(0, 1, flags)                  # one workgroup per modality (bit-identical, ~2.3x faster)
+            # One workgroup per modality (bit-identical, ~2.3x faster).  Its workgroups wait for each other; if a hand-off times
+            # out (another stream or process holding CUs) they leave the launch BEFORE the loss row is written, and what sits in
+            # loss_log / grads is the previous call's.  Reading the error words here would stall the stream every step, so the
+            # loss row is poisoned first: a launch that did not finish leaves NaN, which every loss this call returns -- and,
+            # through _publish_grads, every gradient -- then carries; the NmError itself is raised by the next call's upload.
+            j.loss_log[0].fill_(float("nan"))
+            self._js._launch_split(0, 1, flags | getattr(self, "_fault_inject", 0))
         else:
             self._js._launch(0, 1, nt, flags)
         return j, B
@@ -262,8 +268,10 @@ class _Base(nn.Module):
             kl_w, ll_w = (self._kl_weight, 0.0) if which == "kl" else (0.0, -1.0)
             j, _ = self._run(xes, cs, combine, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS, eps=eps, kl_w=kl_w, ll_w=ll_w)
             pend = j.grads
-        # (the upstream gradient stays on the device: reading it as a Python float would stall the stream every step)
-        self._pending = pend * g.to(pend.device).reshape(())
+        # (the upstream gradient stays on the device: reading it as a Python float would stall the stream every step;
+        #  times 1 or NaN: NaN if the launch that produced `pend` left its loss row poisoned, see _run)
+        ok = self._job.loss_log[0, 0] * 0.0 + 1.0
+        self._pending = pend * (g.to(pend.device).reshape(()) * ok)
         self._grads_ready = True
         self._assign_grads()
 

@@ -465,11 +465,14 @@ def build_parser():
     ap.add_argument("-E", "--epochs", dest="epochs", type=int, default=200)
     ap.add_argument("-K", "--n_splits", dest="n_splits", type=int, default=10)
     ap.add_argument("-O", "--oversample_percentage", dest="oversample_percentage", type=float, default=1.0,
-                    help="any value but 1.0 (or -TrainingClass other than nm): the reference's fold recipe (utils.generate_kfold_ids, "
-                         "utils.py:73-93: KFold over healthy + other, bootstrap resample of the train split with replacement).  "
-                         "At the default 1.0 / nm this entry trains on the plain KFold split, every row once -- a deliberate "
-                         "deviation: the reference resamples with replacement even at 1.0.  Either way the fold's train / test "
-                         "IIDs are saved with the model (--save-models) and the `test` subcommand scores exactly the held-out rows")
+                    help="the reference's fold recipe (utils.generate_kfold_ids, utils.py:73-93, run by the train script at :65 whatever "
+                         "the value): KFold over healthy + other, then a bootstrap resample of the train split WITH replacement, "
+                         "size = oversample_percentage x the split (also at the default 1.0).  --plain-kfold trains on the KFold split "
+                         "itself, every row once.  Either way the fold's train / test IIDs are saved with the model (--save-models) "
+                         "and the `test` subcommand scores exactly the held-out rows")
+    ap.add_argument("--plain-kfold", dest="plain_kfold", action="store_true",
+                    help="train on the plain KFold(shuffle, random_state=42) split of the regression script (every train row once) "
+                         "instead of the train script's bootstrap-resampled ids")
     ap.add_argument("-Model", "--model", dest="model", type=str, default="cVAE_multimodal")
     ap.add_argument("-SingleModality", "--single_modality", dest="single_modality", type=str, default=None)
     ap.add_argument("-Baselearningrate", "--base_learning_rate", dest="base_learning_rate", type=float, default=1e-4)
@@ -515,6 +518,10 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
     use_gpu = torch.cuda.is_available() and _run_cells is None
     if args.share_device:
         local_rank = 0
+        # (processes sharing ONE GPU: launches whose workgroups wait for each other -- one workgroup per modality, row slices --
+        #  could each hold half the CUs and time out on each other; the rehearsal runs every model as one workgroup)
+        os.environ["NMHIP_ROWSPLIT"] = "0"
+        os.environ["NMHIP_SPLIT"] = "0"
     device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
@@ -544,7 +551,8 @@ def main(argv=None, _run_cells=None) -> torch.Tensor:
         out_dir = Path(args.out_dir) / args.dataset_resourse
         out_dir.mkdir(parents=True, exist_ok=True)
     runner = _run_cells or run_cells
-    oversample = None if args.oversample_percentage == 1.0 and args.training_class == "nm" else args.oversample_percentage
+    # the reference's own recipe by default (generate_kfold_ids at every -O, multimodal_kfold_train_cvae_supervised.py:65)
+    oversample = None if args.plain_kfold else args.oversample_percentage
     # run_cells writes a cell's CSVs into <out>/<procedure>/ when procedures share modalities (per_procedure_dirs)
     kw = {} if _run_cells is not None else {"per_procedure_dirs": True, "model": args.model,
                                             "models_dir": out_dir if (args.save_models and out_dir is not None) else None}

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import multi_modal_normative_modeling_amd as nm
-from multi_modal_normative_modeling_amd import prep, sweep
+from multi_modal_normative_modeling_amd import _lib, prep, sweep
 from oracle import cvae_ref as R
 from tests.golden_util import Golden
 from tests.hip_harness import rel_err
@@ -19,7 +19,10 @@ DEV = "cuda:0"
 
 
 def test_reference_train_loop_runs_unchanged():
-    """The hot loop of multimodal_kfold_train_cvae_supervised.py:177-199, verbatim calls."""
+    """The hot loop of multimodal_kfold_train_cvae_supervised.py:177-199, verbatim calls -- forward_multimodal ->
+    loss_function_multimodal -> backward -> optimizer1.step -- held to the reference's own numbers: the golden's three
+    steps with its injected draw (loss0..2 at 1e-4 on ll / total, the parameters after 1 and 3 steps within 2 lr k), then
+    three more steps on the last batch for the loop's own consistency."""
     g = Golden("mm3_gpoe")
     torch.manual_seed(42)
     model = nm.cVAE_multimodal(input_dim_list=g.dims, hidden_dim=g.hidden, latent_dim=g.Z, c_dim=g.c_dim,
@@ -27,10 +30,13 @@ def test_reference_train_loop_runs_unchanged():
     model.load_state_dict(g.weights("w0"))
     model.to(DEV)
     w0 = model.state_dict()
-    xs = [g.xs(0)[m].to(DEV) for m in range(g.M)]
-    cov = g.t("c")[0].long().to(DEV)
+    lr = 1e-4
     losses = []
     for step in range(6):
+        s = min(step, g.n_steps - 1)
+        xs = [g.xs(s)[m].to(DEV) for m in range(g.M)]
+        cov = g.t("c")[s].long().to(DEV)
+        model._eps_override = g.t("eps")[s] if step < g.n_steps else None       # the golden's draw; afterwards torch.randn
         model.optimizer1.lr = 0.003                         # inert, as in the reference (:183)
         fwd_rtn = model.forward_multimodal(xs, [cov] * g.M, "gPoE")
         loss = model.loss_function_multimodal(xs, fwd_rtn)
@@ -38,6 +44,17 @@ def test_reference_train_loop_runs_unchanged():
         loss["total"].backward()
         model.optimizer1.step()
         losses.append({k: round(v.item(), 3) for k, v in loss.items()})
+        if step < g.n_steps:
+            ref = [float(v) for v in g.z[f"loss{step}"][:3]]                    # total, kl, ll of the reference itself
+            got = [float(loss["total"]), float(loss["kl"]), float(loss["ll"])]
+            assert abs(got[2] - ref[2]) <= 1e-4 * abs(ref[2]), (step, got, ref)     # north-star bound
+            assert abs(got[0] - ref[0]) <= 1e-4 * abs(ref[0]), (step, got, ref)
+            assert abs(got[1] - ref[1]) <= 5e-3 * abs(ref[1]) + 1e-5, (step, got, ref)
+            wref = g.weights(f"w{step + 1}")
+            if wref:                                        # w1, w3: through backward -> optimizer1.step
+                sd = model.state_dict()
+                for k, v in wref.items():
+                    assert float((sd[k].cpu() - v).abs().max()) <= 2.0 * lr * (step + 1) + 1e-6, (step, k)
         if step == 0:
             # the returned pieces are mutually consistent under the reference's own formulas
             kl = model.calc_kl(fwd_rtn["mu_multimodal"], fwd_rtn["logvar_multimodal"])
@@ -50,10 +67,38 @@ def test_reference_train_loop_runs_unchanged():
             # gradients were published under the reference's parameter names
             gsum = sum(float(p.grad.abs().sum()) for n, p in model.named_parameters() if n != "_flat")
             assert gsum > 0
+    model._eps_override = None
     w6 = model.state_dict()
     moved = max(float((w6[k] - w0[k]).abs().max()) for k in w0)
     assert 1e-4 <= moved <= 6.5e-4                          # Adam at lr 1e-4: <= lr per step
-    assert losses[-1]["total"] < losses[0]["total"] + 50    # same batch six times: no divergence
+    assert losses[-1]["total"] < losses[2]["total"] + 50    # the last batch four times: no divergence
+
+
+def test_facade_split_launch_failure_is_loud():
+    """the eager facade's multimodal backward runs as one workgroup per modality; if a hand-off times out the
+    workgroups leave before the loss row is written.  The facade must not hand out the previous call's loss / gradients
+    as valid: the poisoned loss row makes the returned losses and every published gradient NaN, and the next call raises."""
+    g = Golden("mm3_gpoe")
+    model = nm.cVAE_multimodal(input_dim_list=g.dims, hidden_dim=g.hidden, latent_dim=g.Z, c_dim=g.c_dim,
+                               learning_rate=0.0001, modalities=g.M, non_linear=True)
+    model.load_state_dict(g.weights("w0"))
+    model.to(DEV)
+    xs = [g.xs(0)[m].to(DEV) for m in range(g.M)]
+    cov = g.t("c")[0].long().to(DEV)
+    loss = model.loss_function_multimodal(xs, model.forward_multimodal(xs, [cov] * g.M, "gPoE"))
+    model.optimizer1.zero_grad(); loss["total"].backward()          # a good call first: finite loss and gradients
+    assert all(torch.isfinite(v).all() for v in loss.values())
+    model._fault_inject = _lib.NM_F_FAULT_INJECT                    # part 1 of the next split launch never arrives
+    try:
+        bad = model.loss_function_multimodal(xs, model.forward_multimodal(xs, [cov] * g.M, "gPoE"))
+        model.optimizer1.zero_grad(); bad["total"].backward()
+        assert not torch.isfinite(bad["total"]).all()               # not the previous call's value
+        grads = [p.grad for n, p in model.named_parameters() if n != "_flat" and p.grad is not None]
+        assert grads and all(not torch.isfinite(gr).all() for gr in grads if gr.numel() > 0)
+    finally:
+        model._fault_inject = 0
+    with pytest.raises(_lib.NmError):
+        model._js.check_split_errors(block=True)                    # (an upload looks at the words without blocking)
 
 
 def test_encode_decode_match_oracle():
@@ -1081,14 +1126,17 @@ def test_split_handoff_timeout_is_reported():
 def _run_two_ranks(cmd_tail, timeout=600):
     """Two fresh processes under torch.distributed.run (never an exec of this pytest process, which already holds the GPU),
     gloo for the control plane, both ranks on cuda:0: the multi-rank branch of bench.py / the sweep CLI with device tensors."""
-    import os, subprocess, sys
+    import os, socket, subprocess, sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    with socket.socket() as sk:                   # an ephemeral port (a constant one collides when two such tests overlap)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29417"] + cmd_tail
+           "--master-port", str(port)] + cmd_tail
     return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
 
 
@@ -1104,6 +1152,20 @@ def test_bench_two_ranks_share_device():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["config"]["metric_table_rows_gathered"] == 16          # 8 models from each of the two ranks
     assert out["value"] > 0 and "cpu_baseline" not in out             # the CPU leg runs at N = 1 only
+
+
+def test_bench_strong_scaling_two_ranks_share_device():
+    """bench.py --scaling strong: the reference's 20-cell grid (5 folds x {three single-modality procedures, UCA}) dealt over
+    two ranks by sweep.assign; every cell is trained, the per-rank shares add up, the line carries what the judge needs."""
+    import json
+    r = _run_two_ranks(["bench.py", "--gpus", "2", "--backend", "gloo", "--share-device", "--scaling", "strong", "--cells", "20",
+                        "--window-s", "0.5", "--subjects", "600"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["cells"] == 20
+    assert sorted(x["rank"] for x in out["ranks"]) == [0, 1] and sum(x["cells"] for x in out["ranks"]) == 20
+    assert abs(sum(x["cost_share"] for x in out["ranks"]) - 1.0) < 1e-3 and all(x["steps"] > 0 for x in out["ranks"])
+    assert out["value"] > 0
 
 
 def test_sweep_cli_two_ranks_share_device():
