@@ -277,6 +277,15 @@ int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int s
 int nm_rowsplit_ok(const nm_job_t* job_host);
 /* Zero the hand-off words of every job (first 256 bytes of workspace tile 0); the split launches call it themselves. */
 int nm_sync_reset(const nm_job_t* jobs_dev, int n_jobs, void* stream);
+/* The ROI-wise deviation pass as its own kernel (csrc/nm_devpass.hip; multimodal_kfold_train_cvae_supervised_regression.py:163-192,
+ * utils_vae.py:147-152): the unimodal encoder -> sampled z -> decoder of a ONE-expert job over table rows [tile0 * 128,
+ * (tile0 + n_tiles) * 128), writing mod[0].out_sqerr / out_rowdev / out_loc and nothing else (no loss log, no latent exports).
+ * 128-row tiles, 75 KB of LDS: two workgroups per CU; 16-row tiles past the table's end are skipped.  Row by row the same
+ * arithmetic and draws as nm_forward (bit-identical exports).  Every job of the launch must pass nm_devpass_ok (host-side
+ * check: -22 = needs nm_forward: several experts, first hidden width > 112, latent > 32, non-Gaussian output, ...). */
+int nm_devpass(const nm_job_t* jobs_dev, int n_jobs, int tile0, int n_tiles, int flags, void* stream);   /* flags: 0 or NM_F_TRACE */
+int nm_trace_read_dv(unsigned long long* out512, int reset);
+int nm_devpass_ok(const nm_job_t* job_host);
 /* NM_F_TRACE read-out of the row-split kernels ([8 waves][64 tags], as nm_trace_read) */
 int nm_trace_read_rs(unsigned long long* out512, int reset);
 /* out_dev[j] (device, n_jobs ints) != 0: a hand-off of job j timed out in a split launch since the word was last

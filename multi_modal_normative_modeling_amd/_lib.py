@@ -130,6 +130,9 @@ def load():
     lib.nm_rowsplit_ok.argtypes = [C.POINTER(NmJob)]
     lib.nm_sync_reset.argtypes = [vp, i32, vp]
     lib.nm_trace_read_rs.argtypes = [C.POINTER(C.c_ulonglong), i32]
+    lib.nm_devpass.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.nm_trace_read_dv.argtypes = [C.POINTER(C.c_ulonglong), i32]
+    lib.nm_devpass_ok.argtypes = [C.POINTER(NmJob)]
     lib.nm_combine_latent.argtypes = [vp, vp, i32, i64, i32, vp, i32, i32, i32, f32, vp, vp, vp]
     lib.nm_total_correlation.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.nm_train_steps.argtypes = [vp, i32, i32, i32, vp]
@@ -167,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_wgtimes_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
     "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split", "nm_launch_wide", "nm_split_errors", "nm_combine_latent", "nm_total_correlation",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
-    "nm_launch_rowsplit", "nm_rowsplit_ok", "nm_sync_reset", "nm_trace_read_rs",
+    "nm_launch_rowsplit", "nm_rowsplit_ok", "nm_sync_reset", "nm_trace_read_rs", "nm_devpass", "nm_devpass_ok", "nm_trace_read_dv",
 ]
 
 

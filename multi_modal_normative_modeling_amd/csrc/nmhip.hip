@@ -978,6 +978,7 @@ const char* nm_status_string(int status) {
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -20: return "row-split launch: the job uses a switch that needs the whole batch in one workgroup, or lacks gpart / workspace tiles";
+    case -22: return "deviation-pass kernel: one expert with the single-expert bypass, first hidden width <= 112, latent <= 32, Gaussian output only";
     case -21: return "n_params must be set and stay below 2^30 floats (32-bit byte offsets into params / adam_m / adam_v)";
     case -15: return "wsh (shadow images) missing: allocate nm_fill_shadow() bytes, zero them and call nm_sync_shadow()";
     case -8: return "bad launch geometry";

@@ -635,9 +635,34 @@ class JobSet:
         else:
             self._launch(s, 1, 1, flags, scalar_tr)
 
-    def forward(self, tile0: int = 0, n_tiles: Optional[int] = None):
-        """forward-only over row tiles (one workgroup per (job, 256-row tile)); fills the exports."""
+    def devpass_ok(self) -> bool:
+        """Can the set's deviation pass run on the compact kernel (nm_devpass: 128-row tiles, two workgroups per CU)?"""
+        if self.wide or os.environ.get("NMHIP_DEVPASS", "1") == "0":
+            return False
+        key = tuple(j._version for j in self.jobs)    # (the check builds every descriptor: once per state of the set, not per launch)
+        if getattr(self, "_devpass_key", None) != key:
+            ok = True
+            for j in self.jobs:
+                if j.out_mu is not None or j.out_logvar is not None or j.out_z is not None:
+                    ok = False                        # (latent exports: the general forward kernel writes them)
+                    break
+                j._ensure_workspace(1)
+                if self.lib.nm_devpass_ok(C.byref(j.struct())) != 0:
+                    ok = False
+                    break
+            self._devpass_key, self._devpass_val = key, ok
+        return self._devpass_val
+
+    def forward(self, tile0: int = 0, n_tiles: Optional[int] = None, loss: bool = True):
+        """forward-only over row tiles (one workgroup per (job, 256-row tile)); fills the exports.  loss=False: only the
+        per-ROI / per-subject deviations and the reconstruction are wanted (the deviation pass of
+        ..._regression.py:163-192) -- one-expert sets then run on the compact kernel, two workgroups per CU."""
         nt = self.jobs[0].tables[0].n_tiles if n_tiles is None else n_tiles
+        if not loss and self.devpass_ok():
+            ptr = self._upload(1)
+            _lib.check(self.lib.nm_devpass(ptr, len(self.jobs), int(tile0) * 2, int(nt) * 2, int(getattr(self, "_dv_flags", 0)),
+                                           _stream_ptr(self.device)), "nm_devpass")
+            return
         self._launch(tile0, 1, nt, _lib.NM_F_EXPORT)
 
     def head_regression(self, backward: bool, grads: bool = True, adam: bool = False, step: int = 0, tile0: int = 0,

@@ -204,7 +204,7 @@ def deviation_roiwise_many(views, cohort: prep.SyntheticCohort, device, want_mat
     for i, o in enumerate(ones):
         by_tiles.setdefault(o.tables[0].n_tiles, []).append(i)
     for idxs in by_tiles.values():
-        JobSet([ones[i] for i in idxs]).forward()
+        JobSet([ones[i] for i in idxs]).forward(loss=False)      # (one-expert views: the compact deviation-pass kernel)
     torch.cuda.synchronize(device)
     out = []
     for one in ones:
@@ -230,7 +230,7 @@ def deviation_roiwise(job: Job, m: int, cohort: prep.SyntheticCohort, name: str,
     table = Table(x, c, device)
     one = Job(spec1, [table], combine="poe", state=st, seed=job.seed + 7919 * (m + 1), n_tiles_ws=table.n_tiles)
     one.enable_exports(loc=False, sqerr=want_matrix, rowdev=True, latent=False)
-    JobSet([one]).forward()
+    JobSet([one]).forward(loss=False)
     torch.cuda.synchronize(device)
     dev = one.out_sqerr[0][: table.N].cpu().numpy() if want_matrix else None
     return dev, one.out_rowdev[0][: table.N].clone(), cohort.iid

@@ -103,11 +103,11 @@ for j in range(a.jobs):
     job.enable_exports(loc=False, sqerr=True, rowdev=True, latent=False)
     djobs.append(job)
 djs = nm.JobSet(djobs)
-djs.forward(); torch.cuda.synchronize()
+djs.forward(loss=False); torch.cuda.synchronize()          # (the compact deviation-pass kernel: nm_devpass)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(8):
-    djs.forward()
+    djs.forward(loss=False)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 8
 rows = N * a.jobs
