@@ -232,6 +232,13 @@ class Job:
             self._gpart_k = k
             self._version += 1
 
+    def devpass_ok(self) -> bool:
+        """nm_devpass_ok for this job, plus: no latent exports asked for (the general forward kernel writes those)."""
+        s = self.spec
+        return (not s.wide and len(self.kmods) == 1 and s.M == 1 and self.single_bypass and s.n_private == 0 and not s.is_dm
+                and self.tc_weight == 0.0 and s.kind != "weighted_dmvae" and s.hidden[0] <= 112 and (s.latent + 15) // 16 * 16 <= 32
+                and self.out_mu is None and self.out_logvar is None and self.out_z is None)
+
     def rowsplit_ok(self) -> bool:
         """Can this model run row-split (nm_rowsplit_ok: plain cVAE / cVAE_multimodal-type models on the fused kernel)?"""
         s = self.spec
@@ -636,22 +643,12 @@ class JobSet:
             self._launch(s, 1, 1, flags, scalar_tr)
 
     def devpass_ok(self) -> bool:
-        """Can the set's deviation pass run on the compact kernel (nm_devpass: 128-row tiles, two workgroups per CU)?"""
+        """Can the set's deviation pass run on the compact kernel (nm_devpass: 128-row tiles, two workgroups per CU)?
+        The conditions of nm_devpass_ok, read off the jobs (building 256 descriptors per launch to ask the library would
+        cost more than the pass; tests/test_cabi_cpu.py holds the two to each other)."""
         if self.wide or os.environ.get("NMHIP_DEVPASS", "1") == "0":
             return False
-        key = tuple(j._version for j in self.jobs)    # (the check builds every descriptor: once per state of the set, not per launch)
-        if getattr(self, "_devpass_key", None) != key:
-            ok = True
-            for j in self.jobs:
-                if j.out_mu is not None or j.out_logvar is not None or j.out_z is not None:
-                    ok = False                        # (latent exports: the general forward kernel writes them)
-                    break
-                j._ensure_workspace(1)
-                if self.lib.nm_devpass_ok(C.byref(j.struct())) != 0:
-                    ok = False
-                    break
-            self._devpass_key, self._devpass_val = key, ok
-        return self._devpass_val
+        return all(j.devpass_ok() for j in self.jobs)
 
     def forward(self, tile0: int = 0, n_tiles: Optional[int] = None, loss: bool = True):
         """forward-only over row tiles (one workgroup per (job, 256-row tile)); fills the exports.  loss=False: only the

@@ -75,6 +75,18 @@ def test_validate_job_limits(lib):
         bad = _probe()
         bad.n_params = n
         assert lib.nm_validate_job(C.byref(bad)) == -21
+    # deviation-pass kernel: one expert with the bypass, first hidden width <= 112, latent <= 32, Gaussian output
+    ok = _probe()
+    ok.w_off, ok.single_bypass = -1, 1
+    assert lib.nm_devpass_ok(C.byref(ok)) == 0
+    for field, val in (("M", 2), ("single_bypass", 0), ("n_private", 1), ("tc_weight", 1e-4), ("w_off", 0), ("out_kind", 1), ("wide", 1), ("Z", 33)):
+        bad = _probe()
+        bad.w_off, bad.single_bypass = -1, 1
+        setattr(bad, field, val)
+        assert lib.nm_devpass_ok(C.byref(bad)) == -22, field
+    bad = _probe(H=(113, 110))
+    bad.w_off, bad.single_bypass = -1, 1
+    assert lib.nm_devpass_ok(C.byref(bad)) == -22
     # row-split launch: plain multimodal models with a partial-gradient buffer only
     ok = _probe(M=3)
     ok.w_off, ok.gpart, ok.gpart_stride = -1, 4096, 118528
