@@ -38,7 +38,7 @@ def kernel_src_sha16() -> str:
     """Identity of the kernel source the loaded library was built from (bench <-> PMC record match)."""
     h = hashlib.sha256()
     csrc = ROOT / "multi_modal_normative_modeling_amd" / "csrc"
-    for p in (csrc / "nm_core.inc", csrc / "nmhip.hip", csrc / "nm_rowsplit.hip", csrc / "nm_wide.inc", ROOT / "include" / "nmhip.h"):
+    for p in (csrc / "nm_core.inc", csrc / "nmhip.hip", csrc / "nm_rowsplit.hip", csrc / "nm_devpass.hip", csrc / "nm_wide.inc", ROOT / "include" / "nmhip.h"):
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
 

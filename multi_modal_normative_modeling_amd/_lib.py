@@ -120,6 +120,8 @@ def load():
     lib.nm_xb_elems.restype = i64
     lib.nm_xb_elems.argtypes = [i32, i32]
     lib.nm_workspace_bytes.argtypes = [C.POINTER(NmJob)]
+    lib.nm_workspace_offset.restype = i64
+    lib.nm_workspace_offset.argtypes = [C.POINTER(NmJob), i32]
     lib.nm_validate_job.argtypes = [C.POINTER(NmJob)]
     for name in ("nm_launch", "nm_launch_scalar_tr"):
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32, i32, vp]
@@ -170,7 +172,7 @@ EXPORTED_SYMBOLS = [
     "nm_test_gemm", "nm_prof_read", "nm_trace_read", "nm_wgtimes_read", "nm_head_regression", "nm_head_classifier", "nm_train_steps_head", "nm_train_steps_persistent", "nm_deviation", "nm_posthoc_metrics", "nm_confusion_metrics",
     "nm_fill_shadow", "nm_sync_shadow", "nm_xb_elems", "nm_launch_split", "nm_launch_wide", "nm_split_errors", "nm_combine_latent", "nm_total_correlation",
     "nm_prep_scaler_fit", "nm_prep_onehot", "nm_pack_table_raw",
-    "nm_launch_rowsplit", "nm_rowsplit_ok", "nm_sync_reset", "nm_trace_read_rs", "nm_devpass", "nm_devpass_ok", "nm_trace_read_dv",
+    "nm_launch_rowsplit", "nm_rowsplit_ok", "nm_sync_reset", "nm_trace_read_rs", "nm_devpass", "nm_devpass_ok", "nm_trace_read_dv", "nm_workspace_offset",
 ]
 
 

@@ -18,6 +18,7 @@ All arithmetic runs in libnmhip.so; there is no CPU fallback (NmError without a 
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Sequence
 
 import numpy as np
@@ -114,10 +115,14 @@ class _Base(nn.Module):
     # -- module tree with the reference's parameter names (views into the flat buffer) --------------
     def _views(self):
         """name -> view into the natural flat buffer; built once per buffer (to() replaces the buffer and rebuilds)."""
+        # (keyed on the storage, not on the Parameter object: nn.Module._apply -- .cuda(), .float(), .to(dtype) -- and
+        #  `_flat.data = ...` swap the storage under the same Parameter, ADVICE r3)
         vc = self.__dict__.get("_view_cache")
-        if vc is None or vc[0] is not self._flat:
-            vc = (self._flat, self.layout.nat_views(self._flat.data))
+        key = (self._flat.data_ptr(), self._flat.device, self._flat.dtype)
+        if vc is None or vc[0] != key:
+            vc = (key, self.layout.nat_views(self._flat.data))
             self.__dict__["_view_cache"] = vc
+            self.__dict__["_nat_grads"] = None
         return vc[1]
 
     def _build_tree(self):
@@ -334,6 +339,31 @@ class _ExpertOps:
         if mu.shape != var.shape or mu.dim() < 2:
             raise ValueError(f"mus / variances must be [M, ...] tensors of equal shape, got {tuple(mu.shape)} / {tuple(var.shape)}")
         M, n = int(mu.shape[0]), int(mu[0].numel())
+        # The launch builds no autograd graph.  The reference's methods are plain differentiable torch (cVAE.py:986-1083,
+        # 1144-1164), so inputs that carry a graph take the same arithmetic as a torch expression: rare -- the
+        # train step differentiates inside the kernel -- but then silently detaching would be wrong.
+        if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (mus, variances)):
+            var_t = torch.exp(var) if in_log else var
+            if M == 1 and bypass:
+                return mu[0], var_t[0]
+            if combine == "moe":
+                omu, ovar = mu.mean(0), var_t.mean(0)
+            else:
+                w = 1.0 / var_t
+                if combine == "gpoe":
+                    if M != self.modalities:
+                        raise ValueError(f"gpoe needs one expert per modality ({self.modalities}), got {M}")
+                    al = torch.softmax(torch.cat([self._views()[f"alpha_m_list.{m}"].reshape(1) for m in range(M)]).to(dev), 0)
+                    w = al.reshape((M,) + (1,) * (mu.dim() - 1)) * w
+                S = w.sum(0)
+                omu, ovar = (mu * w).sum(0) / S, 1.0 / S
+                if combine == "mopoe":
+                    omu, ovar = (mu.sum(0) + omu) / (M + 1), (var_t.sum(0) + ovar) / (M + 1)
+            if out_log:
+                ovar = torch.log(ovar)
+            if floor > 0:
+                ovar = torch.clamp(ovar, min=floor)
+            return omu, ovar
         alpha = None
         if combine == "gpoe":                       # softmax(alpha_m_list) inside the kernel (cVAE.py:1155)
             alpha = torch.cat([self._views()[f"alpha_m_list.{m}"].reshape(1) for m in range(self.modalities)]).to(dev).contiguous()
@@ -511,8 +541,8 @@ class mvtCAE(cVAE_multimodal):
     alpha_m_list; no single-expert bypass; `combine='poe'` is ProductOfExperts2 fed with the VARIANCES where it expects
     log variances (:1782-1783 -- kept as written: NM_COMBINE_POE2V); the joint variance is clamped at 1e-6; the loss is
     sum_i [kl + 1e-5 ll_i + 1e-4 tc] (the log-likelihood with a plus sign, :1877), tc = the total-correlation term of
-    :1862-1869 whose joint half is identically zero.  `qz_xs` (the experts' means) is not returned (None): the loss is
-    formed inside the kernel."""
+    :1862-1869 whose joint half is identically zero.  `qz_xs` = the experts' stacked means, as the reference returns them
+    (read back from the kernel's workspace); the loss itself is formed inside the kernel."""
 
     def __init__(self, input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate=0.0001, modalities=3, non_linear=False):
         super().__init__(input_dim_list, hidden_dim, latent_dim, c_dim, learning_rate, modalities, non_linear)
@@ -559,7 +589,16 @@ class mvtCAE(cVAE_multimodal):
 
     def forward_multimodal(self, xes, cs, combine):
         out = super().forward_multimodal(xes, cs, self._kernel_combine(combine))
-        out["qz_xs"], out["qz_x"] = None, out["mu_multimodal"]
+        # 'qz_xs': the stacked per-expert means [M, B, Z] (cVAE.py:1845) -- the fused kernels leave them in the job's workspace
+        j = self._job
+        off = int(_lib.load().nm_workspace_offset(C.byref(j.struct()), 0)) if not self.spec.wide else -1
+        if off >= 0:
+            M, Z, Zs, B = self.spec.M, self.spec.latent, (self.spec.latent + 15) // 16 * 16, int(out["mu_multimodal"].shape[0])
+            raw = j._ws[off: off + M * _lib.NM_BATCH * Zs * 4].view(torch.float32).view(M, _lib.NM_BATCH, Zs)
+            out["qz_xs"] = raw[:, :B, :Z].clone()
+        else:
+            out["qz_xs"] = None
+        out["qz_x"] = out["mu_multimodal"]
         return out
 
     def loss_function_multimodal(self, xes, fwd_rtn):

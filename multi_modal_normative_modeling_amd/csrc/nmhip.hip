@@ -1085,6 +1085,14 @@ int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
   return (int)hipGetLastError();
 }
 
+/* Where a tile's workspace keeps the experts' statistics after a launch of the fused kernels: byte offset of
+ * mu_m (what = 0) / logvar_m (what = 1), fp32 [step parity][expert][256][Z rounded to 16]; < 0: none (general-shape jobs). */
+int64_t nm_workspace_offset(const nm_job_t* j, int what) {
+  if (!j || j->wide || what < 0 || what > 1) return -1;
+  const WsLayout w = ws_layout(j->M, j->L, j->Z);
+  return what == 0 ? w.mu_m : w.lv_m;
+}
+
 int64_t nm_workspace_bytes(const nm_job_t* j) {
   if (!j) return -1;
   int64_t b = trunk_ws_bytes(j);                      // the head's region sits behind the trunk's

@@ -34,7 +34,7 @@ if tot["FETCH_SIZE"][0] == 0 or tot["WRITE_SIZE"][0] == 0 or tot["FETCH_SIZE"][0
 job_steps = jobs * (steps + warm)                 # every dispatch of the run: warm-up + one timed region
 h = hashlib.sha256()
 csrc = root / "multi_modal_normative_modeling_amd" / "csrc"
-for p in (csrc / "nmhip.hip", csrc / "nm_wide.inc", root / "include" / "nmhip.h"):
+for p in (csrc / "nm_core.inc", csrc / "nmhip.hip", csrc / "nm_rowsplit.hip", csrc / "nm_devpass.hip", csrc / "nm_wide.inc", root / "include" / "nmhip.h"):
     h.update(p.read_bytes())
 fetch = tot["FETCH_SIZE"][1] * 1024 / job_steps
 write = tot["WRITE_SIZE"][1] * 1024 / job_steps

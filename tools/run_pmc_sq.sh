@@ -14,7 +14,8 @@ G4="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
 i=0
 for G in "$G1" "$G2" "$G3" "$G4"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --lean --steps 32 --warmup 4 --repeats 1 --min-warm-s 0 --steps-per-launch 32 > $OUT/g$i.log 2>&1 || true
+  rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-budget 0 --lean --steps 32 --warmup 4 --repeats 1 --min-warm-s 0 --steps-per-launch 32 > $OUT/g$i.log 2>&1 \
+    || { echo "rocprofv3 --pmc group $i failed:"; tail -5 $OUT/g$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections
@@ -25,7 +26,12 @@ for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
             k = row["Counter_Name"]
             agg[k][0] += 1
             agg[k][1] += float(row["Counter_Value"])
+import sys
+want = "$G1 $G2 $G3 $G4".split()
+missing = [k for k in want if agg[k][0] == 0]
 for k, (n, v) in sorted(agg.items()):
     print(f"{k:34s} dispatches {n:3d}  sum {v:.6g}  per-dispatch {v / max(n, 1):.6g}")
+if missing:
+    sys.exit(f"counters without a single nm_step_kernel dispatch: {missing} -- the record is partial")
 PY
 rm -rf $OUT/g1 $OUT/g2 $OUT/g3 $OUT/g4
