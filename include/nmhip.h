@@ -273,10 +273,13 @@ int nm_launch_wide(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_pe
  * flags: NM_F_BACKWARD with NM_F_ADAM (training) or NM_F_GRADS (n_steps == 1: the summed gradients go to job.grads).
  * spread_us > 0 (launches of >= 16 steps): job j starts j / n_jobs of spread_us microseconds late, so that the models of a
  * full chip do not run their Adam sweeps -- the step's burst of memory traffic -- at the same moment (pass ~one step's time).
+ * helpers (0..60): extra workgroups per (model, modality) that take no part in the step itself and only share its Adam
+ * sweep (the sweep of a slice is bound by what one CU pulls from memory; a small set leaves most CUs idle).  Results do
+ * not depend on it (every parameter's update is the same arithmetic whichever workgroup runs it).
  * NM_F_PROFILE: diagnostic, forces write-through stores also inside a group that shares an XCD (A/B of the L2-local path).
- * Status -16: ceil(n_jobs * M / 8) * 8 * k exceeds the CU count; errors of the hand-offs: nm_split_errors. */
-int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int step0, int n_steps, int flags, int spread_us,
-                       void* stream);
+ * Status -16: ceil(n_jobs * M / 8) * 8 * (k + helpers) exceeds the CU count; errors of the hand-offs: nm_split_errors. */
+int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int helpers, int step0, int n_steps, int flags,
+                       int spread_us, void* stream);
 /* 0: the job can run row-split; -20: it uses a switch that needs the whole batch in one workgroup (total correlation,
  * learnable loss weights, private latents, sigmoid output, decoder-only modalities, head models, general-shape path) */
 int nm_rowsplit_ok(const nm_job_t* job_host);

@@ -128,7 +128,7 @@ def load():
     lib.nm_launch_split.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_launch_wide.argtypes = [vp, i32, i32, i32, i32, i32, vp]
     lib.nm_split_errors.argtypes = [vp, i32, vp, i32, vp]
-    lib.nm_launch_rowsplit.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.nm_launch_rowsplit.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.nm_rowsplit_ok.argtypes = [C.POINTER(NmJob)]
     lib.nm_sync_reset.argtypes = [vp, i32, vp]
     lib.nm_trace_read_rs.argtypes = [C.POINTER(C.c_ulonglong), i32]

@@ -53,19 +53,23 @@ struct SwTab {
 };
 static_assert(sizeof(SwTab) % 16 == 0 && (int)sizeof(SwTab) <= STAGE_FLOATS * 4 && (int)sizeof(SwTab) <= WS_RS_TAB_BYTES, "sweep tables fit S and their workspace slot");
 
-// pass number -> geometry, in the order run_step issues the passes
+// pass number -> geometry, in the order the NEXT forward reads the shadow images the sweep rewrites: the first encoder layer's
+// chunks -- read right behind hand-off D -- are the sweep's oldest stores (swept last, as the backward issues the passes,
+// the first chunk waited ~2 us longer for lines still on their way)
 __device__ __forceinline__ WgGeom sw_geom(const nm_job_t* J, int m, int g) {
   const nm_modality_t& md = J->mod[m];
-  const int L = J->L, nck = (md.D + OCH - 1) / OCH;
-  if (g < nck) return geom_out(J, md, g, nullptr);
-  g -= nck;
-  if (g < L) return geom_dec(J, md, L - 1 - g, nullptr);
+  const int L = J->L, nck = (md.D + OCH - 1) / OCH, nch = (md.Kx + XCH - 1) / XCH;
+  if (m < experts(J)) {
+    if (g < nch) return geom_l0(J, md, g, nullptr);
+    g -= nch;
+    if (g < L - 1) return geom_enc(J, md, 1 + g, nullptr);
+    g -= L - 1;
+    if (g < 2) return geom_head(J, md, g, nullptr);
+    g -= 2;
+  }
+  if (g < L) return geom_dec(J, md, g, nullptr);
   g -= L;
-  if (g < 2) return geom_head(J, md, g, nullptr);
-  g -= 2;
-  if (g < L - 1) return geom_enc(J, md, L - 1 - g, nullptr);
-  g -= L - 1;
-  return geom_l0(J, md, g, nullptr);
+  return geom_out(J, md, g, nullptr);
 }
 // vector segment number -> segment: per output chunk its bias and its logvar_out columns, the decoder layers' biases, then
 // the encoder's (heads, hidden layers, first layer) and alpha
@@ -119,20 +123,24 @@ __device__ __forceinline__ void rs_build_tables(const Ctx& cc, int m, GAS char* 
     tab->npass = npass; tab->ntot = acc; tab->nseg = nseg; tab->vtot = off;
   }
   lds_barrier();
-  for (int i = c.tid; i < (int)sizeof(SwTab) / 16; i += WG)
-    *(GAS u32x4*)(gtab + i * 16) = reinterpret_cast<const u32x4*>(tab)[i];
+  for (int i = c.tid; i < (int)sizeof(SwTab) / 16; i += WG)       // (write-through: the helpers read slice 0's copy)
+    st16_wt(gtab + i * 16, reinterpret_cast<const f32x4*>(tab)[i]);
   handoff_barrier();
 }
 
+// The sweep is dealt over KH >= KS workgroups: the KS row slices of the modality and, when the set leaves CUs idle, KH - KS
+// HELPER workgroups that take no part in the step itself (c.rsq = this workgroup's index among the KH).
 template <int KS>
-__device__ __forceinline__ void rs_sweep(const Ctx& cc, int m, const GAS char* gtab) {
+// (tpre: this thread's 16 bytes of the tables, requested by the caller BEFORE hand-off C so that the round trip to the
+//  workspace -- a step's traffic has pushed the tables out of the L2 -- runs under the wait)
+__device__ __forceinline__ void rs_sweep(const Ctx& cc, int m, u32x4 tpre, int KH) {
   Ctx c = cc;
   relaunder(c);
   const nm_job_t* J = c.job;
   SwTab* const tab = reinterpret_cast<SwTab*>(c.stage);
+  static_assert((int)sizeof(SwTab) / 16 <= WG, "one 16-byte piece of the tables per thread");
   lds_barrier();                                   // S is drained by whatever ran before
-  for (int i = c.tid; i < (int)sizeof(SwTab) / 16; i += WG)
-    reinterpret_cast<u32x4*>(tab)[i] = *(const GAS u32x4*)(gtab + i * 16);
+  if (c.tid < (int)sizeof(SwTab) / 16) reinterpret_cast<u32x4*>(tab)[c.tid] = tpre;
   lds_barrier();
   const SwRec* const rec = tab->rec;
   const int* const tbase = tab->tbase;
@@ -141,9 +149,9 @@ __device__ __forceinline__ void rs_sweep(const Ctx& cc, int m, const GAS char* g
   const bool do_adam = (c.flags & NM_F_ADAM) != 0, do_grads = (c.flags & NM_F_GRADS) != 0;
   const AdamK ak = adam_consts(c);
   gf32 Pp = asg(J->params), Mp = asg(J->adam_m), Vp = asg(J->adam_v);
-  const GAS float* const g0 = c.gpart - (int64_t)c.rsq * c.gp_stride;      // slice 0's partials
+  const GAS float* const g0 = asg((const float*)J->gpart);                   // slice 0's partials
   const unsigned gstride_b = (unsigned)(c.gp_stride << 2);                  // (k * gpart_stride * 4 < 2^32: nm_rowsplit_ok)
-  const int stride = KS * NWAVES;
+  const int stride = KH * NWAVES;
   const int prow = c.lane >> 2, pcol = (c.lane & 3) * 4;
   const unsigned lane16 = (unsigned)c.lane << 4;
   constexpr int L = 3 + KS;                                                  // vector-memory operations of one request
@@ -156,7 +164,7 @@ __device__ __forceinline__ void rs_sweep(const Ctx& cc, int m, const GAS char* g
   float vg[SW_NV][KS], vp[SW_NV], vm[SW_NV], vv[SW_NV];
 #pragma unroll
   for (int i = 0; i < SW_NV; ++i) {
-    const int e0 = (i * KS + c.rsq) * WG + c.tid;
+    const int e0 = (i * KH + c.rsq) * WG + c.tid;
     vidx[i] = -1; vcopy[i] = nullptr; vp[i] = 0.f; vm[i] = 0.f; vv[i] = 0.f;
 #ifdef NM_RS_NO_VEC
     if (false) {
@@ -259,18 +267,48 @@ __device__ __forceinline__ void rs_sweep(const Ctx& cc, int m, const GAS char* g
   }
 }
 
+// A helper's side of hand-off C: it has nothing to publish, so it only waits for the counter (bounded, as split_handoff),
+// then acquires.  Returns false on a time-out / when another workgroup of the job has given up.
+__device__ __forceinline__ bool wait_counter(const Ctx& c, GAS unsigned* cnt, GAS unsigned* err, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (c.tid == 0) {
+    int spins = 0;
+    bool ok = true;
+    while (__hip_atomic_load((unsigned*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1 << 22) || __hip_atomic_load((unsigned*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store((unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *c.abort = ok ? 0u : 1u;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  return *c.abort == 0u;
+}
+
 // ---- kernel ----------------------------------------------------------------------------------------------------------
 // Grid: groups of KS workgroups = the row slices of one (job, modality), every group on ONE XCD (workgroups b and b + 8
 // share an XCD -- observed placement, speed only: the partials of a group then meet in that XCD's L2; correctness comes from
-// the hand-off protocol): workgroup b = ((slot * KS + q) << 3) + xcd runs slice q of group slot * 8 + xcd = job * M + m.
+// the hand-off protocol): workgroup b = ((slot * KH + q) << 3) + xcd is member q of group slot * 8 + xcd = job * M + m; members
+// q < KS are the row slices, members KS <= q < KH = KS + H are HELPERS: a small set leaves most CUs idle, and the Adam sweep --
+// a quarter of a slice's step, bound by what ONE CU pulls from memory -- needs nothing but the partials in memory, so the
+// idle CUs take a share of its tiles.  A helper waits for hand-off C (it publishes nothing), sweeps, arrives at D.
 template <int KS>
 __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ jobs, int step0, int n_steps, int flags,
-                                                   int n_jobs, int M, int spread_us) {
+                                                   int n_jobs, int M, int spread_us, int H) {
   constexpr int RTV = 8 / KS;
   NM_GEOM(RTV);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int KH = KS + H;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int q = idx % KS, group = (idx / KS) * 8 + xcd;
+  const int q = idx % KH, group = (idx / KH) * 8 + xcd;
+  const bool helper = q >= KS;
   const int job_idx = group / M, part = group - job_idx * M;
   if (job_idx >= n_jobs) return;
   if ((flags & NM_F_FAULT_INJECT) && part == M - 1 && q == KS - 1) return;   // diagnostic: a workgroup that never arrives
@@ -287,14 +325,14 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
   c.t_last = 0;
   c.rsk = KS; c.rsq = q; c.rloc0 = q * ROWS; c.xwg = 1; c.gwt = 1;
   c.ws0 = (GAS char*)J->workspace;
-  c.ws = c.ws0 + (int64_t)q * J->workspace_stride;
+  c.ws = c.ws0 + (int64_t)(helper ? 0 : q) * J->workspace_stride;          // (a helper has no workspace tile of its own)
   c.gp_stride = J->gpart_stride;
-  c.gpart = (GAS float*)J->gpart + (int64_t)q * J->gpart_stride;
+  c.gpart = (GAS float*)J->gpart + (int64_t)(helper ? 0 : q) * J->gpart_stride;
   for (int i = c.tid; i < SMEM_BYTES / 4; i += WG) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
   const WsLayout wl = ws_layout(J->M, J->L, J->Z);
-  GAS char* const gtab = c.ws + wl.rs_tab + (int64_t)part * WS_RS_TAB_BYTES;
-  rs_build_tables(c, part, gtab);
+  GAS char* const gtab = c.ws + wl.rs_tab + (int64_t)part * WS_RS_TAB_BYTES;    // (helpers: slice 0's tables, complete at D below)
+  if (!helper) rs_build_tables(c, part, gtab);
 #ifdef NM_RS_DEBUG_TABLES
   {   // diagnostic build: dump the table header of workgroup (job 0, part 0, slice 0) into the loss log and leave
     if (blockIdx.x == 0 && c.tid == 0 && J->loss_log) {
@@ -316,17 +354,14 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
   // coherence point -- the group's internal payload (gradient partials, shadow images) is stored plain and served from
   // that L2 instead of being written through to memory and fetched back at the cross-XCD rate.  A placement that differs
   // from the expected one (workgroups b and b + 8 on one XCD) costs speed, never correctness.
+  // (one word per modality part in tile 0: every member ORs in the bit of its XCD; one bit set = one XCD)
   {
     const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;
-    GAS unsigned* const my = (GAS unsigned*)(c.ws + wl.sync) + WS_SYNC_XCC_WORD + part;
-    if (c.tid == 0) __hip_atomic_store(my, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!split_handoff(c, sync_d, sync_err, (unsigned)KS)) return;
-    bool same = true;
-    for (int qq = 0; qq < KS; ++qq) {
-      const unsigned o = __hip_atomic_load((GAS unsigned*)(c.ws0 + (int64_t)qq * J->workspace_stride + wl.sync) + WS_SYNC_XCC_WORD + part,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      same = same && o == xcc + 1u;
-    }
+    GAS unsigned* const word = sync0 + WS_SYNC_XCC_WORD + part;
+    if (c.tid == 0) __hip_atomic_fetch_or((unsigned*)word, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!split_handoff(c, sync_d, sync_err, (unsigned)KH)) return;
+    const unsigned seen = __hip_atomic_load((unsigned*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = seen == (1u << xcc);
     c.gwt = (same && !(flags & NM_F_PROFILE)) ? 0 : 1;        // (NM_F_PROFILE here: force the write-through path, for A/B runs)
   }
   // start offsets: the models of a full chip otherwise reach their Adam sweeps -- the step's burst of memory traffic --
@@ -337,6 +372,7 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
   }
   const int nb = (J->n_rows + TROWS - 1) / TROWS;
+  float ss_lane = 0.f, ib_lane = 0.f;
   for (int s = step0; s < step0 + n_steps; ++s) {
     const int b = s % nb;
     c.lstep = s - step0;
@@ -344,42 +380,72 @@ __global__ __launch_bounds__(WG) void nm_rs_kernel(const nm_job_t* __restrict__ 
     c.row0 = b * TROWS + c.rloc0;
     c.nrows = max(0, min(ROWS, brows - c.rloc0));               // ... of this slice (0: a slice past a ragged batch's end)
     c.inv_b = 1.0f / (float)brows;                              // means run over the whole batch
-    const int64_t t_opt = J->adam_off + (int64_t)s + 1;
-    const double tt = (double)t_opt;
-    const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
-    c.step_size = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
-    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+    // Adam's step constants (double precision, as torch forms them): two pow() calls are ~2 us of dependent arithmetic --
+    // 2 % of a 100-us step -- so every 64 steps lane l of each wave computes those of step s + l, and a step reads its lane
+    if ((c.lstep & 63) == 0) {
+      const int64_t t_opt = J->adam_off + (int64_t)s + 1 + c.lane;
+      const double tt = (double)t_opt;
+      const double lr_t = (J->lr_table && J->lr_cap > 0) ? J->lr_table[(t_opt - 1) % J->lr_cap] : (double)J->lr;
+      ss_lane = (float)(lr_t / (1.0 - pow((double)J->beta1, tt)));
+      ib_lane = (float)(1.0 / sqrt(1.0 - pow((double)J->beta2, tt)));
+    }
+    c.step_size = __shfl(ss_lane, c.lstep & 63, 64);
+    c.inv_bc2_sqrt = __shfl(ib_lane, c.lstep & 63, 64);
     if (flags & 64) c.tlast[c.wave_s] = clock64();
     lds_barrier();
     relaunder(c);
-    run_step<false, 0, RTV>(c, s);
-    if (*c.abort != 0u) break;                                  // a hand-off timed out (wave-uniform: LDS word read by all)
-    tr(c, 40);
-    // C: every workgroup of the model has stored its partials and loss shares
-    if (!split_handoff(c, sync_c, sync_err, (unsigned)(c.lstep + 1) * (unsigned)(M * KS))) break;
+    u32x4 tpre = {0u, 0u, 0u, 0u};
+    if (helper) {
+      if (c.tid < (int)sizeof(SwTab) / 16) tpre = *(const GAS u32x4*)(gtab + c.tid * 16);
+      if (!wait_counter(c, sync_c, sync_err, (unsigned)(c.lstep + 1) * (unsigned)(M * KS))) break;
+    } else {
+      run_step<false, 0, RTV>(c, s);
+      if (*c.abort != 0u) break;                                // a hand-off timed out (wave-uniform: LDS word read by all)
+      if (c.tid < (int)sizeof(SwTab) / 16) tpre = *(const GAS u32x4*)(gtab + c.tid * 16);
+      tr(c, 40);
+      // C: every workgroup of the model has stored its partials and loss shares
+      if (!split_handoff(c, sync_c, sync_err, (unsigned)(c.lstep + 1) * (unsigned)(M * KS))) break;
+      // the next step's first x chunks travel while the sweep runs (P and Q are dead until then)
+      c.x_pre = 0;
+      if (s + 1 < step0 + n_steps) {
+        const nm_modality_t& md = J->mod[part];
+        const int bn = (s + 1) % nb;
+        c.x_pre = fwd_first_layer_prefetch<RTV>(c, (const GAS char*)asg(md.xb) + (int64_t)bn * ((md.Kx + XCH - 1) / XCH) * XIMG_TILE_BYTES +
+                                                       (int64_t)c.rloc0 * (LDX * 2), md.Kx);
+      }
+    }
     tr(c, 41);
-    if (part == 0 && q == 0 && c.tid == 0 && J->loss_log) {     // loss row: the slices' shares, in slice order
+    // loss row: the slices' shares (word 0: KL, word 1 + m: log-likelihood of modality m), summed in slice order by the
+    // model's first workgroup.  Lane qq * (1 + M) + w of its wave 0 requests share w of slice qq now and the row is formed
+    // after the sweep (the next step rewrites the shares only after hand-off D): the round trip is off the step's path.
+    const bool loss_wg = part == 0 && q == 0 && c.wave_s == 0 && J->loss_log != nullptr;
+    float share = 0.f;
+    if (loss_wg && c.lane < KS * (1 + M)) {
+      const int qq = c.lane / (1 + M), w = c.lane - qq * (1 + M);
+      share = ((const GAS float*)(c.ws0 + (int64_t)qq * J->workspace_stride + wl.sync))[WS_SYNC_LOSS_WORD + w];
+    }
+    rs_sweep<KS>(c, part, tpre, KH);
+    if (loss_wg) {                                              // (wave-uniform)
       gf32 row = asg(J->loss_log) + (int64_t)(s % J->loss_cap) * NM_LOSS_STRIDE;
       float kl = 0.f, ll_sum = 0.f;
-      for (int qq = 0; qq < KS; ++qq)
-        kl += ((const GAS float*)(c.ws0 + (int64_t)qq * J->workspace_stride + wl.sync))[WS_SYNC_LOSS_WORD];
+      for (int qq = 0; qq < KS; ++qq) kl += __shfl(share, qq * (1 + M), 64);
       for (int m = 0; m < M; ++m) {
         float ll = 0.f;
-        for (int qq = 0; qq < KS; ++qq)
-          ll += ((const GAS float*)(c.ws0 + (int64_t)qq * J->workspace_stride + wl.sync))[WS_SYNC_LOSS_WORD + 1 + m];
-        row[NM_LOSS_LL_M + m] = ll;
+        for (int qq = 0; qq < KS; ++qq) ll += __shfl(share, qq * (1 + M) + 1 + m, 64);
+        if (c.lane == 0) row[NM_LOSS_LL_M + m] = ll;
         ll_sum += ll;
       }
-      row[NM_LOSS_KL] = J->kl_weight * kl;
-      row[NM_LOSS_LL] = ll_sum;
-      row[NM_LOSS_TC] = 0.f;
-      row[15] = (float)c.gwt;                                   // (diagnostic: 0 = the group's payload stayed in one XCD's L2)
-      row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
+      if (c.lane == 0) {
+        row[NM_LOSS_KL] = J->kl_weight * kl;
+        row[NM_LOSS_LL] = ll_sum;
+        row[NM_LOSS_TC] = 0.f;
+        row[15] = (float)c.gwt;                                 // (diagnostic: 0 = the group's payload stayed in one XCD's L2)
+        row[NM_LOSS_TOTAL] = J->kl_weight * kl - J->ll_weight * ll_sum;
+      }
     }
-    rs_sweep<KS>(c, part, gtab);
     tr(c, 42);
     // D: the modality's new shadow images / vector pieces are complete (the next forward of every slice reads them)
-    if (!split_handoff(c, sync_d, sync_err, (unsigned)(c.lstep + 2) * (unsigned)KS)) break;    // (arrival 1: the placement check)
+    if (!split_handoff(c, sync_d, sync_err, (unsigned)(c.lstep + 2) * (unsigned)KH)) break;    // (arrival 1: the placement check)
     tr(c, 43);
   }
   if ((flags & 64) && blockIdx.x < 512 && c.tid == 0) nm_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
@@ -392,8 +458,8 @@ extern "C" {
 /* Row-split launch (include/nmhip.h): n_jobs models of M modalities each, k in {2, 4} row slices per (model, modality).
  * Every job needs k workspace tiles and gpart / gpart_stride; -16: the launch would not be resident at once;
  * -20: a job of the launch cannot run row-split (see nm_rowsplit_ok). */
-int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int step0, int n_steps, int flags, int spread_us,
-                       void* stream) {
+int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int helpers, int step0, int n_steps, int flags,
+                       int spread_us, void* stream) {
   if (!jobs_dev) return -1;
   if (n_jobs < 1 || n_steps < 1 || step0 < 0 || M < 1 || M > NM_MAX_EXP || (k != 2 && k != 4)) return -8;
   if (!(flags & NM_F_BACKWARD) || !(flags & (NM_F_ADAM | NM_F_GRADS))) return -8;
@@ -401,8 +467,9 @@ int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int s
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return -8;
+  if (helpers < 0 || helpers > 60) return -8;
   const int groups = (n_jobs * M + 7) / 8 * 8;
-  const int wgs = groups * k;
+  const int wgs = groups * (k + helpers);
   if (wgs > cus) return -16;            // the workgroups of a model wait for each other: all must be resident
   hipStream_t st = (hipStream_t)stream;
   nm_sync_reset(jobs_dev, n_jobs, stream);
@@ -412,11 +479,11 @@ int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int s
   if (k == 2) {
     e = hipFuncSetAttribute((const void*)nm_rs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nm_rs_kernel<2>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M, spread_us);
+    hipLaunchKernelGGL(nm_rs_kernel<2>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M, spread_us, helpers);
   } else {
     e = hipFuncSetAttribute((const void*)nm_rs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nm_rs_kernel<4>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M, spread_us);
+    hipLaunchKernelGGL(nm_rs_kernel<4>, dim3(wgs), dim3(WG), SMEM_BYTES, st, jobs_dev, step0, n_steps, flags, n_jobs, M, spread_us, helpers);
   }
   return (int)hipGetLastError();
 }

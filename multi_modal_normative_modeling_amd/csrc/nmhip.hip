@@ -924,7 +924,7 @@ __global__ __launch_bounds__(WG) void test_gemm_kernel(int mode, const float* A,
 // ================================= C ABI ========================================================
 extern "C" {
 
-int nm_version(void) { return 9; }
+int nm_version(void) { return 10; }
 
 /* phase profile (NM_F_PROFILE): read / reset the per-phase shader-clock accumulators */
 int nm_prof_read(unsigned long long* out32, int reset) {

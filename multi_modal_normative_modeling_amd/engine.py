@@ -585,21 +585,34 @@ class JobSet:
                 return k
         return 1
 
-    def _launch_rowsplit(self, k: int, step0: int, n_steps: int, flags: int):
+    def rowsplit_helpers(self, k: int) -> int:
+        """Helper workgroups per (model, modality) of a row-split launch: the CUs the k slices leave idle join the Adam
+        sweep (nmhip.h: nm_launch_rowsplit).  A group stays on one XCD (32 CUs); measured (one and five 3 x 379 models,
+        k = 4): 6 helpers give all of the gain, beyond 12 the extra arrivals at the hand-off cost what the shorter sweep
+        saves -- so at most 12.  NMHIP_RS_HELPERS pins it."""
+        env = os.environ.get("NMHIP_RS_HELPERS", "auto")
+        if not hasattr(self, "_cus"):
+            self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        groups = (len(self.jobs) * len(self.jobs[0].kmods) + 7) // 8 * 8
+        room = max(0, min(self._cus // groups, 32) - k)
+        return min(int(env), room) if env != "auto" else min(room, 12)
+
+    def _launch_rowsplit(self, k: int, step0: int, n_steps: int, flags: int, helpers: Optional[int] = None):
         for j in self.jobs:
             j._ensure_rowsplit(k)
         ptr = self._upload(k)
+        h = self.rowsplit_helpers(k) if helpers is None else int(helpers)
         # start offsets over ~one step's time once the launch fills a good part of the chip (measured: 0.37 ns per
         # parameter and step for one model at k = 4); NMHIP_RS_SPREAD scales it, 0 switches it off
         wgs = len(self.jobs) * len(self.jobs[0].kmods) * k
         scale = float(os.environ.get("NMHIP_RS_SPREAD", "1"))
         spread = int(self.jobs[0].layout.n_params * 0.37e-3 * (4 / k) * scale) if wgs >= 96 else 0
-        _lib.check(self.lib.nm_launch_rowsplit(ptr, len(self.jobs), len(self.jobs[0].kmods), int(k), int(step0), int(n_steps),
+        _lib.check(self.lib.nm_launch_rowsplit(ptr, len(self.jobs), len(self.jobs[0].kmods), int(k), h, int(step0), int(n_steps),
                                                int(flags), spread, _stream_ptr(self.device)), "nm_launch_rowsplit")
         self._split_pending = True
 
     def train(self, n_steps: int, scalar_tr: bool = False, profile: bool = False, split: Optional[bool] = None,
-              rowsplit: Optional[int] = None):
+              rowsplit: Optional[int] = None, helpers: Optional[int] = None):
         """n_steps fused train steps per job in ONE launch (forward + ELBO + backward + Adam).  Small sets put several
         workgroups behind a model: k row slices per (model, modality) (rowsplit=None: rowsplit_k(); results agree with the
         one-workgroup launch to fp32 summation order), else one workgroup per modality (split=None: automatically;
@@ -610,7 +623,7 @@ class JobSet:
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_ADAM | (_lib.NM_F_PROFILE if profile else 0)
         k = (self.rowsplit_k() if split is None else 1) if rowsplit is None else int(rowsplit)
         if k > 1 and not scalar_tr:
-            self._launch_rowsplit(k, step0, n_steps, flags)
+            self._launch_rowsplit(k, step0, n_steps, flags, helpers)
             for j in self.jobs:
                 j.step += n_steps
                 j.t += n_steps
@@ -628,12 +641,12 @@ class JobSet:
             j.t += n_steps
 
     def grads(self, step: Optional[int] = None, export: bool = True, scalar_tr: bool = False, split: bool = False,
-              rowsplit: int = 1):
+              rowsplit: int = 1, helpers: Optional[int] = None):
         """forward + loss + backward for one step; gradients land in job.grads (no update)."""
         s = self.jobs[0].step if step is None else step
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | (_lib.NM_F_EXPORT if export else 0)
         if rowsplit > 1:
-            self._launch_rowsplit(rowsplit, s, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS)
+            self._launch_rowsplit(rowsplit, s, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS, helpers)
         elif split:
             ptr = self._upload(1)
             _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), len(self.jobs[0].kmods), int(s), 1, int(flags),

@@ -141,18 +141,18 @@ def test_rowsplit_one_launch_equals_stepwise_and_is_reproducible(name, k):
     launches through the kernel boundary -- any stale read inside the launch shows as a difference."""
     g = Golden(name)
     res = []
-    for mode in ("fused", "stepwise", "fused"):
+    for mode in ("fused", "stepwise", "fused", "no helpers", "3 helpers"):
         job = _table_job(g, 600, seed=5)
         js = nm.JobSet([job])
-        if mode == "fused":
-            js.train(7, rowsplit=k)
-        else:
+        if mode == "stepwise":
             for _ in range(7):
                 js.train(1, rowsplit=k)
+        else:       # (default: every idle CU of the group's XCD helps with the Adam sweep -- same arithmetic per parameter)
+            js.train(7, rowsplit=k, helpers={"no helpers": 0, "3 helpers": 3}.get(mode))
         js.check_split_errors(block=True)
         torch.cuda.synchronize()
         res.append((job.params.cpu().clone(), job.adam_m.cpu().clone(), job.adam_v.cpu().clone(), job.loss_log[:7].cpu().clone()))
-    for other, what in ((res[1], "stepwise"), (res[2], "second run")):
+    for other, what in ((res[1], "stepwise"), (res[2], "second run"), (res[3], "no helpers"), (res[4], "3 helpers")):
         for a, b, t in zip(res[0], other, ("params", "adam_m", "adam_v", "loss_log")):
             assert torch.equal(a, b), (what, t, float((a - b).abs().max()))
     # and the trajectory is the whole-batch launch's up to summation order
@@ -192,7 +192,7 @@ def test_rowsplit_many_models_pick_and_refusal():
         j._ensure_rowsplit(2)
     ptr = big._upload(2)
     st = torch.cuda.current_stream().cuda_stream
-    assert _lib.load().nm_launch_rowsplit(ptr, 96, 3, 2, 0, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM, 0, st) == -16
+    assert _lib.load().nm_launch_rowsplit(ptr, 96, 3, 2, 0, 0, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM, 0, st) == -16
 
 
 def test_rowsplit_full_size_se_model_vs_oracle():
