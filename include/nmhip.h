@@ -34,6 +34,7 @@ extern "C" {
 #define NM_MAX_MOD 8     /* decoders per model (SM: 1, SE: 3, UCA: 4, end-to-end: 2 banks x 3)   */
 #define NM_MAX_EXP 4     /* experts = modalities that also have an encoder                        */
 #define NM_MAX_CLS 5       /* hidden blocks of the end-to-end classifier */
+#define NM_MAX_CLS_WIDTH 512   /* width of a classifier block (blocks > 128 wide run in 128-column tiles) */
 #define NM_MAX_CLASSES 4
 #define NM_MAX_HID 8     /* hidden layers per encoder / decoder stack            */
 #define NM_BATCH   256   /* rows per workgroup tile (= reference batch size)      */

@@ -13,6 +13,7 @@ NM_MAX_MOD = 8
 NM_MAX_EXP = 4
 NM_MAX_HID = 8
 NM_MAX_CLS = 5
+NM_MAX_CLS_WIDTH = 512
 NM_MAX_CLASSES = 4
 NM_BATCH = 256
 NM_MAX_WIDTH = 127

@@ -250,8 +250,31 @@ struct ClsWs {
     return (gf32)(base + (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)NM_MAX_CLS * ROWS * PW * 4 + (int64_t)i * PW * 4);
   }
 };
-__host__ __device__ inline int64_t cls_ws_bytes() {
-  return (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)NM_MAX_CLS * ROWS * PW * 4 + (int64_t)NM_MAX_CLS * PW * 4;
+// [256][128] tiles per activation of the classifier: 1 = every block fits the fused head's tile; > 1: blocks wider than 128
+// (-Layers "256 128 64" of commands_list9_endtoend.sh:21) -- cls_head_body_wide, activations in workspace tiles
+__host__ __device__ inline int cls_tiles(const nm_job_t* J) {
+  int tb = 1;
+  for (int i = 0; i < J->cls_layers && i < NM_MAX_CLS; ++i) tb = tb > wblocks(J->cls_width[i]) ? tb : wblocks(J->cls_width[i]);
+  return tb;
+}
+// the tile form of the classifier workspace: inputs of Linear 0 .. NM_MAX_CLS as TB tiles each (bf16), x_hat of every BatchNorm
+// (fp32 tiles), 1 / sigma, and two sets of delta tiles (bf16) the backward alternates between
+struct ClsWsW {
+  GAS char* base;
+  int TB;
+  __device__ __forceinline__ int64_t o_xhat() const { return (int64_t)(NM_MAX_CLS + 1) * TB * WTILE * 2; }
+  __device__ __forceinline__ int64_t o_rstd() const { return o_xhat() + (int64_t)NM_MAX_CLS * TB * WTILE * 4; }
+  __device__ __forceinline__ int64_t o_dy() const { return o_rstd() + (int64_t)NM_MAX_CLS * TB * PW * 4; }
+  __device__ __forceinline__ gbf16 hin(int i) const { return (gbf16)(base + (int64_t)i * TB * WTILE * 2); }
+  __device__ __forceinline__ gf32 xhat(int i) const { return (gf32)(base + o_xhat() + (int64_t)i * TB * WTILE * 4); }
+  __device__ __forceinline__ gf32 rstd(int i) const { return (gf32)(base + o_rstd() + (int64_t)i * TB * PW * 4); }
+  __device__ __forceinline__ gbf16 dy(int s) const { return (gbf16)(base + o_dy() + (int64_t)s * TB * WTILE * 2); }
+};
+__host__ __device__ inline int64_t cls_ws_bytes(const nm_job_t* J) {
+  const int64_t tb = cls_tiles(J);
+  if (tb <= 1) return (int64_t)(NM_MAX_CLS + 1) * ROWS * PW * 2 + (int64_t)NM_MAX_CLS * ROWS * PW * 4 + (int64_t)NM_MAX_CLS * PW * 4;
+  return (int64_t)(NM_MAX_CLS + 1) * tb * WTILE * 2 + (int64_t)NM_MAX_CLS * tb * WTILE * 4 + (int64_t)NM_MAX_CLS * tb * PW * 4 +
+         2 * tb * WTILE * 2;
 }
 // column sums over the rows of per-lane values v[t][i] (feature (wn+4t)*16+4g+i) into dst[feature]
 __device__ __forceinline__ void col_reduce(const Ctx& c, const float (&v)[2][4], float* dst, int N) {
@@ -278,8 +301,19 @@ __device__ __forceinline__ f32x4 uniform4_ctr(uint64_t seed, uint32_t step, uint
   return u;
 }
 
+__device__ __forceinline__ void cls_head_body_wide(Ctx& c, const nm_job_t* J, int step, GAS char* hws, bool log, bool bn_stats);
 // (same contract as reg_head_body; `bn_stats`: update the BatchNorm running statistics)
+// TILED_OK: blocks wider than 128 go to cls_head_body_wide (nm_clshead_kernel); the persistent head kernel compiles the
+// one-tile head only (with both it spills vector registers, which the ISA guard refuses) and marks such a job's loss row
+// NaN instead of running it -- JobSet.train_endtoend sends those models through the three-launch form.
+template <bool TILED_OK>
 __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int step, GAS char* hws, bool log, bool bn_stats) {
+  if (cls_tiles(J) > 1) {
+    if constexpr (TILED_OK) cls_head_body_wide(c, J, step, hws, log, bn_stats);
+    else if (c.tid < NM_LOSS_STRIDE && J->loss_log)
+      asg(J->loss_log)[(int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE + c.tid] = __builtin_nanf("");
+    return;
+  }
   const int flags = c.flags;
   const bool train = J->cls_train != 0;
   const bool bwd = (flags & NM_F_BACKWARD) != 0 && train && J->labels != nullptr;
@@ -623,12 +657,329 @@ __device__ __forceinline__ void cls_head_body(Ctx& c, const nm_job_t* J, int ste
     }
   }
 }
+
+// The same head with blocks wider than 128 (cls_tiles(J) > 1): every activation lives in the workspace as [256][128] bf16
+// tiles, a Linear loops over (output block, input block) with the general-shape path's block GEMMs (nm_wide.inc: weights
+// from the tiled fp32 master, staged as bf16 one block ahead), BatchNorm statistics / ReLU / dropout per output block in the
+// accumulator's lanes exactly as above, the weight gradients + Adam through wide_linear_bwd.  Same arithmetic per element
+// as cls_head_body; a block <= 128 wide gives the same numbers up to the bf16 rounding of the tiles it passes through.
+__device__ __forceinline__ void cls_head_body_wide(Ctx& c, const nm_job_t* J, int step, GAS char* hws, bool log, bool bn_stats) {
+  const int flags = c.flags;
+  const bool train = J->cls_train != 0;
+  const bool bwd = (flags & NM_F_BACKWARD) != 0 && train && J->labels != nullptr;
+  const int Lc = J->cls_layers, C = J->cls_classes, Z = J->Z;
+  const float Bf = (float)c.nrows;
+  gcf32 prm = asg(J->params);
+  float* col1 = c.colacc;
+  float* col2 = c.stage;
+  const ClsWsW W{hws, cls_tiles(J)};
+  const float keep_scale = (train && J->cls_dropout > 0.f) ? 1.0f / (1.0f - J->cls_dropout) : 1.0f;
+  auto zero_P = [&]() {
+    for (int e = c.tid; e < ROWS * (LDP / 8); e += WG) reinterpret_cast<u32x4*>(c.P)[e] = u32x4{0u, 0u, 0u, 0u};
+  };
+
+  // ---- tile 0 of hin(0) <- z (or the joint mean for predict) ----
+  lds_barrier();
+  zero_P();
+  lds_barrier();
+  {
+    gcf32 zsrc = asg((const float*)(J->cls_use_mu ? J->out_mu : J->out_z));
+    const float rk = 1.0f / (float)Z;
+    for (int e = c.tid; e < c.nrows * Z; e += WG) {
+      const int r = idiv(e, Z, rk), k = e - r * Z;
+      c.P[r * LDP + k] = (__bf16)zsrc[(int64_t)(c.row0 + r) * Z + k];
+    }
+  }
+  lds_barrier();
+  store_act(c, W.hin(0), c.P, PW);
+  handoff_barrier();
+
+  f32x4 acc[2][RT];
+  // ---- hidden blocks ----
+  for (int li = 0; li < Lc; ++li) {
+    const int K = li == 0 ? Z : J->cls_width[li - 1], N = J->cls_width[li];
+    gcf32 Wl = prm + J->cls_w[li];
+    for (int nb = 0; nb < wblocks(N); ++nb) {
+      relaunder(c);
+      const int fb = nb * WT, nv = min(WT, N - fb);            // this block: features [fb, fb + nv)
+      float mean[2][4], rstd[2][4], gam[2][4], bet[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int fc = fb + min((c.wn + 4 * t) * 16 + 4 * c.g + i, nv - 1);
+          gam[t][i] = prm[J->cls_bn_w[li] + fc];
+          bet[t][i] = prm[J->cls_bn_b[li] + fc];
+        }
+      bias_acc(c, acc, prm + J->cls_b[li], N, fb);
+      wide_gemm_fwd(c, acc, W.hin(li), (gcbf16)nullptr, 0, Wl, N, K, nb);
+      relaunder(c);
+      if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
+      __syncthreads();                             // P / Q fully read; column accumulators cleared
+      if (train) {                                 // batch statistics over the valid rows (biased variance)
+        float v[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) sm += (c.wm * WROWS + rt * 16 + c.c16 < c.nrows) ? acc[t][rt][i] : 0.f;
+            v[t][i] = sm;
+          }
+        col_reduce(c, v, col1, nv);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int f = min((c.wn + 4 * t) * 16 + 4 * c.g + i, PW - 1);
+            mean[t][i] = col1[f] / Bf;
+            float sm = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              const float d = acc[t][rt][i] - mean[t][i];
+              sm += (c.wm * WROWS + rt * 16 + c.c16 < c.nrows) ? d * d : 0.f;
+            }
+            v[t][i] = sm;
+          }
+        col_reduce(c, v, col2, nv);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = (c.wn + 4 * t) * 16 + 4 * c.g + i, fc = fb + min(f, nv - 1);
+          float var;
+          if (train) { var = col2[min(f, PW - 1)] / Bf; }
+          else { mean[t][i] = prm[J->cls_bn_mean[li] + fc]; var = prm[J->cls_bn_var[li] + fc]; }
+          rstd[t][i] = 1.0f / sqrtf(var + 1e-5f);
+        }
+      if (c.tid < nv && train) {                   // per-feature rstd for the backward pass; running statistics
+        const float m = col1[c.tid] / Bf, var = col2[c.tid] / Bf;
+        if (bwd) W.rstd(li)[fb + c.tid] = 1.0f / sqrtf(var + 1e-5f);
+        if (bn_stats && log) {
+          gf32 rm = asg(J->params) + J->cls_bn_mean[li] + fb + c.tid, rv = asg(J->params) + J->cls_bn_var[li] + fb + c.tid;
+          const float unb = c.nrows > 1 ? var * Bf / (Bf - 1.0f) : var;
+          *rm = 0.9f * *rm + 0.1f * m;
+          *rv = 0.9f * *rv + 0.1f * unb;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int r = c.wm * WROWS + rt * 16 + c.c16;
+          f32x4 xh;
+          bf16x4 pk;
+          f32x4 u4 = {1.f, 1.f, 1.f, 1.f};
+          if (train && J->cls_dropout > 0.f)
+            u4 = uniform4_ctr(J->seed, (uint32_t)step, (uint32_t)li, (uint32_t)(c.row0 + r), (uint32_t)((fb + f0) >> 2));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            xh[i] = (acc[t][rt][i] - mean[t][i]) * rstd[t][i];
+            float h = fmaxf(gam[t][i] * xh[i] + bet[t][i], 0.f);
+            if (train && J->cls_dropout > 0.f) h = u4[i] >= J->cls_dropout ? h * keep_scale : 0.f;
+            pk[i] = (__bf16)((f0 + i < nv && r < c.nrows) ? h : 0.f);
+          }
+          if (bwd) *(GAS f32x4*)(W.xhat(li) + (int64_t)nb * WTILE + r * PW + f0) = xh;
+          *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
+        }
+      }
+      lds_barrier();
+      store_act(c, W.hin(li + 1) + (int64_t)nb * WTILE, c.P, PW);
+    }
+    handoff_barrier();                             // the block's tiles are read back by the next Linear
+  }
+
+  tr(c, 26);
+  // ---- output layer, cross entropy ----
+  relaunder(c);
+  const int Kl = Lc ? J->cls_width[Lc - 1] : Z;
+  bias_acc(c, acc, prm + J->cls_b[Lc], C, 0);
+  wide_gemm_fwd(c, acc, W.hin(Lc), (gcbf16)nullptr, 0, prm + J->cls_w[Lc], C, Kl, 0);
+  relaunder(c);
+  lds_barrier();
+  zero_P();                                        // d logits land here
+  lds_barrier();
+  float ce = 0.f;
+  if (c.wn == 0 && c.g == 0) {                     // these lanes hold logits 0..3 of their rows
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int r = c.wm * WROWS + rt * 16 + c.c16;
+      if (r < c.nrows) {
+        float l[NM_MAX_CLASSES], mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < NM_MAX_CLASSES; ++k) { l[k] = acc[0][rt][k]; if (k < C) mx = fmaxf(mx, l[k]); }
+        if (J->out_logits)
+#pragma unroll
+          for (int k = 0; k < NM_MAX_CLASSES; ++k)
+            asg(J->out_logits)[(int64_t)(c.row0 + r) * NM_MAX_CLASSES + k] = k < C ? l[k] : 0.f;
+        if (J->labels) {
+          const int y = asg(J->labels)[c.row0 + r];
+          float se = 0.f;
+#pragma unroll
+          for (int k = 0; k < NM_MAX_CLASSES; ++k) se += k < C ? expf(l[k] - mx) : 0.f;
+          const float lse = mx + logf(se);
+#pragma unroll
+          for (int k = 0; k < NM_MAX_CLASSES; ++k) {
+            if (k == y) ce += lse - l[k];
+            if (bwd && k < C) c.P[r * LDP + k] = (__bf16)((expf(l[k] - lse) - (k == y ? 1.f : 0.f)) * J->cls_w_ce * c.inv_b);
+          }
+        }
+      }
+    }
+  }
+  const float ce_sum = block_sum(c, ce);
+  // ---- contrastive hinge on the per-subject deviations (cVAE.py:2166-2182) ----
+  const int Me = experts(J);
+  float hinge = 0.f;
+  if (J->labels && c.tid < c.nrows && J->M >= 2 * Me) {
+    const int gr = c.row0 + c.tid;
+    float dh = 0.f, dd = 0.f;
+    bool have = true;
+    for (int m = 0; m < Me; ++m) {
+      have = have && J->mod[m].out_rowdev && J->mod[Me + m].out_rowdev;
+      if (have) { dh += asg(J->mod[m].out_rowdev)[gr]; dd += asg(J->mod[Me + m].out_rowdev)[gr]; }
+    }
+    if (have) {
+      dh /= (float)Me; dd /= (float)Me;
+      const int y = asg(J->labels)[gr];
+      const float tval = y ? J->cls_margin + dd - dh : J->cls_margin + dh - dd;
+      hinge = fmaxf(tval, 0.f);
+      if (bwd) {
+        const float gt = tval > 0.f ? J->cls_w_contrast * c.inv_b : 0.f;
+        const float g_h = y ? -gt : gt;
+        for (int m = 0; m < Me; ++m) {
+          if (J->rowcoef_out[m]) asg(J->rowcoef_out[m])[gr] = g_h * 2.0f / ((float)Me * (float)J->mod[m].D);
+          if (J->rowcoef_out[Me + m]) asg(J->rowcoef_out[Me + m])[gr] = -g_h * 2.0f / ((float)Me * (float)J->mod[Me + m].D);
+        }
+      }
+    }
+  }
+  const float hinge_sum = block_sum(c, hinge);
+  if (c.tid == 0 && J->loss_log && J->labels && log) {
+    gf32 row = asg(J->loss_log) + (int64_t)(step % J->loss_cap) * NM_LOSS_STRIDE;
+    row[NM_LOSS_CE] = ce_sum * c.inv_b;
+    row[NM_LOSS_CONTRAST] = hinge_sum * c.inv_b;
+  }
+  tr(c, 27);
+  if (!bwd) return;
+
+  // ---- backward ----
+  lds_barrier();
+  store_act(c, W.dy(0), c.P, PW);                  // d logits as a delta tile
+  handoff_barrier();
+  float* const hpatch = c.stage + SPATCH_OFF / 4;
+  int cur = 0;                                     // dy(cur): delta at the output of Linear li
+  for (int li = Lc; li >= 0; --li) {
+    const int K = li == 0 ? Z : J->cls_width[li - 1], N = li == Lc ? C : J->cls_width[li];
+    gcf32 Wl = prm + J->cls_w[li];
+    gcbf16 dyt = W.dy(cur);
+    if (li > 0) {
+      const int lb = li - 1;                       // the block whose output is Linear li's input
+      for (int kb = 0; kb < wblocks(K); ++kb) {
+        relaunder(c);
+        const int fb = kb * WT, kv = min(WT, K - fb);
+        zero_acc(acc);
+        wide_gemm_dgrad(c, acc, dyt, Wl, N, K, kb);          // d h (pre-mask) of features [fb, fb + kv)
+        relaunder(c);
+        float grs[2][4];                           // gamma * rstd of this lane's features
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int fc = fb + min((c.wn + 4 * t) * 16 + 4 * c.g + i, kv - 1);
+            grs[t][i] = prm[J->cls_bn_w[lb] + fc] * W.rstd(lb)[fc];
+          }
+        if (c.tid < PW) { col1[c.tid] = 0.f; col2[c.tid] = 0.f; }
+        __syncthreads();                           // P / Q fully read; column accumulators cleared
+        gcbf16 ht = W.hin(li) + (int64_t)kb * WTILE;
+        gcf32 xt = W.xhat(lb) + (int64_t)kb * WTILE;
+        float v1[2][4], v2[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v1[t][i] = 0.f; v2[t][i] = 0.f; }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = c.wm * WROWS + rt * 16 + c.c16;
+            const bf16x4 h = *(const GAS bf16x4*)(ht + r * PW + f0);
+            const f32x4 xh = *(const GAS f32x4*)(xt + r * PW + f0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float dy = ((float)h[i] > 0.f && r < c.nrows && f0 + i < kv) ? acc[t][rt][i] * keep_scale : 0.f;
+              acc[t][rt][i] = dy;
+              v1[t][i] += dy;
+              v2[t][i] = fmaf(dy, xh[i], v2[t][i]);
+            }
+          }
+        }
+        col_reduce(c, v1, col1, kv);
+        col_reduce(c, v2, col2, kv);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int f0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+          float s1[4], s2[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s1[i] = col1[min(f0 + i, PW - 1)] * c.inv_b;
+            s2[i] = col2[min(f0 + i, PW - 1)] * c.inv_b;
+          }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = c.wm * WROWS + rt * 16 + c.c16;
+            const f32x4 xh = *(const GAS f32x4*)(xt + r * PW + f0);
+            bf16x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float da = grs[t][i] * (acc[t][rt][i] - s1[i] - xh[i] * s2[i]);
+              pk[i] = (__bf16)((r < c.nrows && f0 + i < kv) ? da : 0.f);
+            }
+            *reinterpret_cast<bf16x4*>(c.P + r * LDP + f0) = pk;
+          }
+        }
+        __syncthreads();                           // gamma has been read by everyone: its update may go ahead
+        if (c.tid < kv) {                          // d gamma = S2, d beta = S1
+          apply_grad(c, J->cls_bn_w[lb] + fb + c.tid, col2[c.tid]);
+          apply_grad(c, J->cls_bn_b[lb] + fb + c.tid, col1[c.tid]);
+        }
+        store_act(c, W.dy(cur ^ 1) + (int64_t)kb * WTILE, c.P, PW);
+      }
+    } else if (J->dz_out) {                        // d CE / d z
+      relaunder(c);
+      zero_acc(acc);
+      wide_gemm_dgrad(c, acc, dyt, Wl, N, K, 0);
+      relaunder(c);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int k0 = (c.wn + 4 * t) * 16 + 4 * c.g;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int r = c.wm * WROWS + rt * 16 + c.c16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (r < c.nrows && k0 + i < Z) asg(J->dz_out)[(int64_t)(c.row0 + r) * Z + k0 + i] = acc[t][rt][i];
+        }
+      }
+    }
+    // the weights of Linear li have been read by the dgrad: their gradient / update
+    wide_linear_bwd(c, dyt, W.hin(li), (gcbf16)nullptr, 0, J->cls_w[li], J->cls_b[li], N, K, false, (gbf16)nullptr, (gf32)nullptr, 0,
+                    0, hpatch);
+    handoff_barrier();
+    cur ^= 1;
+  }
+}
 __global__ __launch_bounds__(WG) void nm_clshead_kernel(const nm_job_t* __restrict__ jobs, int step, int tile0, int flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const nm_job_t* J = jobs + blockIdx.x;
   Ctx c;
   if (!head_setup(c, smem, J, step, tile0, flags & (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS))) return;
-  cls_head_body(c, J, step, c.ws + trunk_ws_bytes(J), blockIdx.y == 0, (flags & NM_F_BNSTATS) != 0);
+  cls_head_body<true>(c, J, step, c.ws + trunk_ws_bytes(J), blockIdx.y == 0, (flags & NM_F_BNSTATS) != 0);
 }
 
 // ---- head models in one persistent launch ------------------------------------------------------------------------
@@ -678,7 +1029,7 @@ __global__ __launch_bounds__(WG) void nm_head_step_kernel(const nm_job_t* __rest
     relaunder(c);
     c.flags = bflags | tflags;
     if (J->reg_head) reg_head_body(c, J, s, hws, true);
-    else if (J->cls_classes > 0) cls_head_body(c, J, s, hws, true, (flags & NM_F_BNSTATS) != 0);
+    else if (J->cls_classes > 0) cls_head_body<false>(c, J, s, hws, true, (flags & NM_F_BNSTATS) != 0);
     handoff_barrier();                            // the head's gradients for the trunk are complete
     tr(c, 29);
     relaunder(c);
@@ -984,7 +1335,7 @@ const char* nm_status_string(int status) {
     case -8: return "bad launch geometry";
     case -9: return "unknown combine";
     case -10: return "parameter tensor offsets must be multiples of 4 floats (weight matrices: of 256)";
-    case -13: return "classifier head: 0..NM_MAX_CLS blocks of width 1..128, 2..NM_MAX_CLASSES classes, offsets multiples of 4, out_mu/out_z export";
+    case -13: return "classifier head: 0..NM_MAX_CLS blocks of width 1..NM_MAX_CLS_WIDTH, 2..NM_MAX_CLASSES classes, offsets multiples of 4, out_mu/out_z export";
     case -12: return "metrics: n_sets >= 1 and 1 <= max_set <= NM_METRICS_MAX_N";
     case -11: return "regression head: needs reg_w / reg_b offsets (weights: multiples of 256, biases: of 4) and the reg_resid / reg_dres image buffers (16-byte aligned)";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown argument error";
@@ -1033,7 +1384,7 @@ int nm_validate_job(const nm_job_t* j) {
   if (j->cls_classes > 0) {
     if (j->cls_layers < 0 || j->cls_layers > NM_MAX_CLS || j->cls_classes < 2 || j->cls_classes > NM_MAX_CLASSES) return -13;
     for (int i = 0; i < j->cls_layers; ++i) {
-      if (j->cls_width[i] < 1 || j->cls_width[i] > PW) return -13;
+      if (j->cls_width[i] < 1 || j->cls_width[i] > NM_MAX_CLS_WIDTH) return -13;
       if ((j->cls_b[i] | j->cls_bn_w[i] | j->cls_bn_b[i] | j->cls_bn_mean[i] | j->cls_bn_var[i]) & 3) return -13;
       if (j->cls_w[i] & 255) return -13;
     }
@@ -1098,7 +1449,7 @@ int64_t nm_workspace_bytes(const nm_job_t* j) {
   int64_t b = trunk_ws_bytes(j);                      // the head's region sits behind the trunk's
   int64_t hb = 0;
   if (j->reg_head) hb = ACT_BYTES;        // regression head: its first hidden activation, kept for the backward pass
-  if (j->cls_layers > 0 || j->cls_classes > 0) hb = hb > cls_ws_bytes() ? hb : cls_ws_bytes();
+  if (j->cls_layers > 0 || j->cls_classes > 0) hb = hb > cls_ws_bytes(j) ? hb : cls_ws_bytes(j);
   return b + (hb + 255) / 256 * 256;
 }
 

@@ -202,6 +202,8 @@ class Job:
         for i, h in enumerate(self.spec.hidden):
             probe.H[i] = h
         probe.cls_layers, probe.cls_classes = len(self.spec.classifier_layers), (self.spec.num_classes if self.spec.classifier_layers else 0)
+        for i, w in enumerate(self.spec.classifier_layers):      # (blocks wider than 128: the head's workspace is in tiles)
+            probe.cls_width[i] = w
         probe.reg_head = 1 if self.spec.kind == "regression" else 0
         probe.M_enc = self.spec.M
         for k, (m, _, _) in enumerate(self.kmods):
@@ -710,7 +712,9 @@ class JobSet:
         exported, (ii) the classifier head: forward (train-mode BatchNorm / Dropout), cross entropy, contrastive
         hinge, backward, its Adam update, d CE / d z and the hinge row coefficients, (iii) the trunk's backward + Adam
         with those extra gradients.  fused (default): one persistent launch for all steps (nm_train_steps_head);
-        fused=False: the three-launches-per-step form it replaced (trunk forward twice), kept as a cross-check."""
+        fused=False: the three-launches-per-step form it replaced (trunk forward twice), kept as a cross-check -- and the
+        form a trunk on the general-shape path or a classifier with blocks wider than 128 (-Layers "256 128 64") runs in:
+        the persistent head kernel holds the one-tile classifier only."""
         step0 = self.jobs[0].step
         for j in self.jobs:
             if j.spec.kind != "endtoend" or not j.spec.classifier_layers or j.labels is None:
@@ -722,7 +726,8 @@ class JobSet:
         nb = self.jobs[0].batches_per_epoch
         if any(j.batches_per_epoch != nb for j in self.jobs):
             raise ValueError("jobs of one set must have the same number of batches")
-        if fused and not self.wide:
+        tiled_head = any(w > 128 for j in self.jobs for w in j.spec.classifier_layers)
+        if fused and not self.wide and not tiled_head:
             self._train_head(step0, n_steps, _lib.NM_F_BNSTATS)
         else:
             for s in range(step0, step0 + n_steps):

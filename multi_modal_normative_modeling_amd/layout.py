@@ -86,8 +86,9 @@ class ModelSpec:
                              f"latent {self.latent}, c_dim {self.net_c_dim}")
         if self.is_dm and len(self.hidden) != 2:
             raise ValueError("the DMVAE family has exactly two hidden layers (hidden_dims[0], hidden_dims[1])")
-        if len(self.classifier_layers) > _lib.NM_MAX_CLS or any(w < 1 or w > 128 for w in self.classifier_layers):
-            raise ValueError(f"classifier_layers: at most {_lib.NM_MAX_CLS} widths in 1..128, got {list(self.classifier_layers)}")
+        if len(self.classifier_layers) > _lib.NM_MAX_CLS or any(w < 1 or w > _lib.NM_MAX_CLS_WIDTH for w in self.classifier_layers):
+            raise ValueError(f"classifier_layers: at most {_lib.NM_MAX_CLS} widths in 1..{_lib.NM_MAX_CLS_WIDTH}, "
+                             f"got {list(self.classifier_layers)}")
         if self.classifier_layers and not (2 <= self.num_classes <= _lib.NM_MAX_CLASSES):
             raise ValueError(f"num_classes must be 2..{_lib.NM_MAX_CLASSES}")
 

@@ -136,6 +136,15 @@ def test_workspace_bytes(lib):
     w1 = lib.nm_workspace_bytes(C.byref(_probe()))
     w3 = lib.nm_workspace_bytes(C.byref(_probe(M=3)))
     assert w1 > 0 and w3 > w1 and w1 % 256 == 0
+    # the classifier head's region: one [256][128] tile per activation, or tiles of blocks wider than 128 (nmhip.h: NM_MAX_CLS_WIDTH)
+    p = _probe(M=3)
+    p.cls_layers, p.cls_classes = 3, 2
+    for i, w in enumerate((128, 64, 32)):
+        p.cls_width[i] = w
+    narrow = lib.nm_workspace_bytes(C.byref(p))
+    p.cls_width[0] = 256
+    tiled = lib.nm_workspace_bytes(C.byref(p))
+    assert narrow > w3 and tiled > narrow + 2 * 256 * 128 * 2
 
 
 def test_param_layout_matches_reference_names():

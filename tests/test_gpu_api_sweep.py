@@ -261,8 +261,15 @@ def test_regression_and_endtoend_command_lines_one_gpu():
         # "-Layers 128 64 32 16" of the same grid (four blocks: NM_MAX_CLS = 5) ...
         res = sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "128", "64", "32", "16"])
         assert len(res) == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
-        with pytest.raises(ValueError):                          # ... and a classifier wider than the head kernel takes
-            sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "256", "128", "64"])
+        # ... "-Layers 256 128 64" and "256 128 64 32 16" (the classifier's first block as two 128-column tiles), the second on
+        # a trunk of the general-shape path: every -Layers list of commands_list9_endtoend.sh:21 constructs and trains
+        res = sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "256", "128", "64"])
+        assert len(res) == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
+        res = sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-H", "200", "200", "10",
+                                   "-Layers", "256", "128", "64", "32", "16"])
+        assert len(res) == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
+        with pytest.raises(ValueError):                          # ... and a classifier wider than the head kernels take
+            sweep.main_endtoend(["-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-Layers", "1024", "64"])
 
 
 def test_train_then_test_command_lines():
@@ -509,7 +516,12 @@ def test_fused_endtoend_training_matches_reference_trajectory():
                                                         ([379, 379, 379], [110, 110], 29, 256, [128, 64, 32]),
                                                         ([60, 45, 70], [300, 160], 5, 200, [128, 64, 32]),   # "-H 300 300 ..": trunk on the general-shape path
                                                         ([60, 45, 70], [40, 32], 5, 200, [128, 64, 32, 16]),  # "-Layers 128 64 32 16"
-                                                        ([60, 45, 70], [40, 32], 5, 83, [100, 90, 64, 40, 24])])
+                                                        ([60, 45, 70], [40, 32], 5, 83, [100, 90, 64, 40, 24]),
+                                                        # blocks wider than 128 (-Layers "256 128 64" / "256 128 64 32 16" of
+                                                        # commands_list9_endtoend.sh:21): the head in 128-column tiles
+                                                        ([60, 45, 70], [40, 32], 5, 200, [256, 128, 64]),
+                                                        ([60, 45, 70], [40, 32], 5, 83, [256, 128, 64, 32, 16]),
+                                                        ([60, 45, 70], [300, 160], 5, 200, [200, 272, 72])])
 def test_classifier_head_config5_shape_vs_oracle(dims, hidden, cdim, B, layers):
     """The end-to-end model with the config-5 head (Z = 64, classifier [128, 64, 32]) at a small trunk with a ragged batch
     of 200 and at BASELINE config 5's full shape (3 x 379 ROI, H = [110, 110], c = 29, batch 256): logits, cross entropy,
@@ -1039,16 +1051,18 @@ def _kernel_dropout_keep(seed, step, layer, rows, width, p):
     return torch.from_numpy((u >= np.float32(p)).astype(np.float32))
 
 
-@pytest.mark.parametrize("dims,hidden,cdim,B,p", [([60, 45, 70], [40, 32], 5, 200, 0.5), ([379, 379, 379], [110, 110], 29, 256, 0.5),
-                                                   ([60, 45, 70], [40, 32], 5, 64, 0.25)])
-def test_classifier_dropout_parity_vs_oracle(dims, hidden, cdim, B, p):
+@pytest.mark.parametrize("dims,hidden,cdim,B,p,layers", [([60, 45, 70], [40, 32], 5, 200, 0.5, [128, 64, 32]),
+                                                          ([379, 379, 379], [110, 110], 29, 256, 0.5, [128, 64, 32]),
+                                                          ([60, 45, 70], [40, 32], 5, 64, 0.25, [128, 64, 32]),
+                                                          ([60, 45, 70], [40, 32], 5, 200, 0.5, [256, 128, 64])])
+def test_classifier_dropout_parity_vs_oracle(dims, hidden, cdim, B, p, layers):
     """Config 5 with the classifier's Dropout ON (the script's dropout_rate = 0.5, multimodal_kfold_cvae_nmpmcont.py:257-268;
     Classifier: cVAE.py:2004-2018).  torch's own mask comes from the global Philox stream and is not reproducible, so the
     comparison injects the kernel's mask into the oracle: the mask is recomputed on the host from the kernel's counter
     hash, and logits, cross entropy, hinge and every gradient of the model are held to the oracle with that mask; plus
     the properties a dropout layer must have -- keep fraction ~ 1 - p, kept activations scaled by 1 / (1 - p) (checked
     through the logits: they match an oracle that scales, and do not match one that does not)."""
-    Z, layers = 64, [128, 64, 32]
+    Z = 64
     torch.manual_seed(11)
     model = nm.cVAE_multimodal_endtoend(dims, hidden, Z, cdim, modalities=3, non_linear=True, classifier_layers=layers,
                                         dropout_rate=p, num_classes=2)
@@ -1282,6 +1296,51 @@ def test_facade_buffer_reuse_is_stateless():
         assert a[0] == b[0] and a[1] == b[1], (B, shared, comb, a[:2], b[:2])
         assert torch.equal(a[2], b[2])
         assert a[3].keys() == b[3].keys() and all(torch.equal(a[3][k], b[3][k]) for k in a[3]), (B, shared, comb)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_endtoend_training_with_256_wide_classifier_matches_oracle_trajectory(fused):
+    """-Layers "256 128 64" (commands_list9_endtoend.sh:21): the classifier's first block is two 128-column tiles.  Two Adam
+    steps of the whole end-to-end model -- in one persistent launch (nm_train_steps_head) and as three launches per step --
+    against the oracle's trajectory (dropout 0)."""
+    dims, hidden, Z, cdim, B, layers = [50, 40, 45], [40, 32], 16, 7, 128, (256, 128, 64)
+    spec = nm.ModelSpec(dims, hidden, Z, cdim, True, "endtoend", layers, 2)
+    assert not spec.wide
+    P = nm.ParamLayout(spec).init_reference_rule(9)
+    g = torch.Generator().manual_seed(19)
+    xs = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.rand(B, cdim, generator=g)
+    labels = (torch.rand(B, generator=g) < 0.4).long()
+    eps = torch.randn(2, 256, Z, generator=g)
+    lr = 1e-3
+    job = nm.Job(spec, [nm.Table(x, c, DEV) for x in xs], combine="poe", state=P, lr=lr, kl_weight=0.1, ll_weight=0.1,
+                 single_bypass=False, loss_cap=4)
+    job.cls_dropout, job.cls_margin, job.cls_w_contrast = 0.0, 1.0, 0.1
+    job.set_labels(labels.int())
+    job.set_eps(eps)
+    js = nm.JobSet([job])
+    js.train_endtoend(2, fused=fused)
+    torch.cuda.synchronize()
+    js.assert_finite()
+    rs = R.Spec(dims, hidden, Z, cdim, True, kind="endtoend", classifier_layers=list(layers))
+    Pr = {k: v.clone() for k, v in P.items()}
+    names = [k for k in R.param_names(rs) if "running" not in k and "num_batches" not in k]
+    opt = R.Adam(Pr, names, lr=lr)
+    R.set_operand_rounding("bf16")
+    try:
+        for s in range(2):
+            leaves = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in Pr.items()}
+            of = R.forward_endtoend(leaves, rs, xs, [c] * 3, eps[s, :B], training=True)
+            ol = R.loss_endtoend(rs, xs, of, labels, margin=1.0, weightcontrastive=0.1)
+            ol["total_loss"].backward()
+            opt.step(Pr, {k: leaves[k].grad for k in names})
+            row = job.loss_log[s].cpu()
+            assert abs(float(row[13]) - float(ol["classification_loss"])) <= 1e-2 * abs(float(ol["classification_loss"])) + 1e-4, s
+    finally:
+        R.set_operand_rounding("fp32")
+    sd = job.state_dict()
+    for k in names:
+        assert float((sd[k] - Pr[k]).abs().max()) <= 2.0 * lr * 2 + 1e-6, k
 
 
 def test_endtoend_training_on_a_wide_trunk_matches_oracle_trajectory():

@@ -67,7 +67,7 @@ def main():
                 tags = {0: "enc first layer", 1: "enc hidden", 2: "enc heads", 3: "handoff A + latent", 4: "z|c", 5: "dec hidden",
                         6: "out: wait+GEMM", 7: "out: epilogue", 8: "out: dlogvar+dgrad", 9: "out: wgrad partial", 10: "dec bwd dgrad",
                         11: "dec bwd wgrad", 12: "handoff B + fusion bwd", 13: "enc bwd prep+heads dgrad", 14: "enc bwd heads/hidden",
-                        15: "enc bwd first layer", 16: "enc first layer: chunk 0 landed", 17: "step prologue", 40: "(tail of run_step)", 41: "handoff C", 44: "sweep: table", 45: "sweep: tiles", 42: "sweep: vectors", 43: "handoff D"}
+                        15: "enc bwd first layer", 16: "enc first layer: chunk 0 landed", 17: "step prologue", 18: "enc first layer: requests issued", 40: "(tail of run_step)", 41: "handoff C", 44: "sweep: table", 45: "sweep: tiles", 42: "sweep: vectors", 43: "handoff D"}
                 tot = [sum(buf[w * 64 + t] for t in range(64)) / 16 for w in range(8)]
                 print(f"   trace ({mode}, {n} models): cycles per step, wave 0 / mean of waves; total {tot[0]:.0f}")
                 for t in range(64):

@@ -68,7 +68,7 @@ LIMITS = {
     "nm_wide_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 300},
     "nm_head_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 580},
     "nm_reghead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 16},
-    "nm_clshead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 24},
+    "nm_clshead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 140},   # (+ the tiled head)
 }
 
 
