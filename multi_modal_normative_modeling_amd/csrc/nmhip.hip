@@ -1006,6 +1006,11 @@ __global__ __launch_bounds__(WG) void nm_head_step_kernel(const nm_job_t* __rest
   __syncthreads();
   GAS char* const hws = c.ws + trunk_ws_bytes(J);
   const int nb = (J->n_rows + ROWS - 1) / ROWS;
+  if (J->wide) {          // a trunk of the general-shape path trains in the three-launch form (JobSet.train_regression / train_endtoend)
+    if (c.tid < NM_LOSS_STRIDE && J->loss_log)
+      for (int s = step0; s < step0 + n_steps; ++s) asg(J->loss_log)[(int64_t)(s % J->loss_cap) * NM_LOSS_STRIDE + c.tid] = __builtin_nanf("");
+    return;
+  }
   const int tflags = flags & (NM_F_PROFILE | NM_F_TRACE);
   // NM_F_GRADS: gradients of the step's total into job.grads, no update (the eager facade's backward)
   const int bflags = NM_F_BACKWARD | ((flags & NM_F_GRADS) ? NM_F_GRADS : NM_F_ADAM);
@@ -1101,7 +1106,7 @@ __global__ void sync_shadow_kernel(const nm_job_t* __restrict__ jobs) {
   const int L = J->L, Z = J->Z, C = J->C, Zs = rup(Z, 16);
   const int Me = J->M_enc > 0 ? J->M_enc : J->M;
   const int BIG = 1 << 30;
-  for (int m = 0; m < J->M; ++m) {
+  for (int m = 0; m < (J->wide ? 0 : J->M); ++m) {             // (general-shape jobs: no trunk images, the fp32 master is read)
     const nm_modality_t& md = J->mod[m];
     if (m < Me) {
       const int nch = (md.Kx + XCH - 1) / XCH;
@@ -1325,7 +1330,7 @@ const char* nm_status_string(int status) {
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
     case -18: return "out_kind must be 0 or 1, 0 <= n_private <= Z, and a private latent needs an encoder per decoder";
-    case -19: return "general-shape path (wide): cVAE / cVAE_multimodal / end-to-end trunk only (no regression head, no DMVAE-family or mvtCAE switches)";
+    case -19: return "general-shape path (wide): cVAE / cVAE_multimodal and the trunks of the end-to-end / regression models only (no DMVAE-family or mvtCAE switches)";
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -20: return "row-split launch: the job uses a switch that needs the whole batch in one workgroup, or lacks gpart / workspace tiles";
@@ -1352,9 +1357,9 @@ int nm_validate_job(const nm_job_t* j) {
     for (int i = 0; i < j->L; ++i)
       if (j->H[i] < 1 || j->H[i] > NM_WIDE_MAX_WIDTH) return -4;
     if (j->Z < 1 || j->Z > NM_WIDE_MAX_LATENT) return -5;
-    // (the classifier head of the end-to-end model runs as its own kernel, nm_head_classifier, on any trunk)
-    if (j->out_kind != 0 || j->n_private != 0 || j->tc_weight != 0.f || j->w_off >= 0 || j->reg_head ||
-        j->combine == NM_COMBINE_POE2V)
+    // (the heads of the end-to-end and the regression model run as their own kernels, nm_head_classifier /
+    //  nm_head_regression, on any trunk)
+    if (j->out_kind != 0 || j->n_private != 0 || j->tc_weight != 0.f || j->w_off >= 0 || j->combine == NM_COMBINE_POE2V)
       return -19;
   } else {
   for (int i = 0; i < j->L; ++i)
@@ -1410,6 +1415,8 @@ int64_t nm_fill_shadow(nm_job_t* j) {
     if (md.Kx < 32 || md.D < 1) return -7;
     for (int i = 0; i < NM_MAX_HID; ++i) { md.enc_s[i] = 0; md.dec_s[i] = 0; }
     md.heads_s = 0;
+    md.out_s = 0;
+    if (j->wide) continue;                         // general-shape trunk: no images (only a regression head's, below)
     if (m < Me) {
       const int nch = (md.Kx + XCH - 1) / XCH;
       md.enc_s[0] = o; o += (int64_t)l0_img_bytes(j->H[0], md.Kx) + VEC_BYTES;

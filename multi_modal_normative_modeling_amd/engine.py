@@ -211,9 +211,9 @@ class Job:
             probe.mod[k].Kx = self.tables[m].Kx
         self.ws_bytes = int(lib.nm_workspace_bytes(C.byref(probe)))
         if self._wsh is None:
-            if self.spec.wide:                       # the general-shape path reads the fp32 master: no shadow images
+            if self.spec.wide and self.spec.kind != "regression":   # the general-shape path reads the fp32 master: no shadow images
                 self._wsh = torch.zeros(256, dtype=torch.uint8, device=self.device)
-            else:
+            else:                                    # (general-shape regression model: the regressor's first-layer images only)
                 nb = int(lib.nm_fill_shadow(C.byref(probe)))
                 if nb < 0:
                     _lib.check(nb, "nm_fill_shadow")
@@ -408,7 +408,7 @@ class Job:
             md.dloc_extra = self.dloc_extra[k].data_ptr() if self.dloc_extra[k] is not None else None
             md.dloc_rowcoef = self.dloc_rowcoef[k].data_ptr() if self.dloc_rowcoef[k] is not None else None
             j.rowcoef_out[k] = md.dloc_rowcoef
-        if not s.wide:
+        if not s.wide or s.kind == "regression":
             nb = int(_lib.load().nm_fill_shadow(C.byref(j)))       # shadow-image offsets of every modality
             if nb != self._wsh.numel():
                 raise _lib.NmError(f"shadow size changed: {nb} vs {self._wsh.numel()} bytes")
@@ -534,9 +534,9 @@ class JobSet:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._dev = host.to(self.device)
             self._sig = sig
-        if self.wide:
+        if self.wide:                                # (no shadow images but a regression head's first layer)
             for j in self.jobs:
-                j.shadow_dirty = False
+                j.shadow_dirty = j.shadow_dirty and j.spec.kind == "regression"
         if any(j.shadow_dirty for j in self.jobs):
             _lib.check(self.lib.nm_sync_shadow(self._dev.data_ptr(), len(self.jobs), _stream_ptr(self.device)), "nm_sync_shadow")
             for j in self.jobs:
@@ -753,13 +753,27 @@ class JobSet:
         nb = self.jobs[0].batches_per_epoch
         if any(j.batches_per_epoch != nb for j in self.jobs):
             raise ValueError("jobs of one set must have the same number of batches")
-        self._train_head(step0, n_steps)
+        if self.wide:
+            # a trunk on the general-shape path: three launches per step (residual images out, the regressor with its
+            # update and d MSE / d x_hat, the trunk's backward + Adam with that extra gradient)
+            for s in range(step0, step0 + n_steps):
+                self._launch(s, 1, 1, _lib.NM_F_EXPORT)
+                self.head_regression(backward=True, grads=False, adam=True, step=s, tile0=s % nb)
+                self._launch(s, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_ADAM)
+        else:
+            self._train_head(step0, n_steps)
         for j in self.jobs:
             j.step += n_steps
             j.t += n_steps
 
     def grads_head(self, step: int = 0, bn_stats: bool = False):
         """Gradients of one head-model step's total loss into job.grads, no update (the eager facade's backward)."""
+        if self.wide:                      # (regression model on a general-shape trunk: the three-launch form)
+            nb = self.jobs[0].batches_per_epoch
+            self._launch(step, 1, 1, _lib.NM_F_EXPORT)
+            self.head_regression(backward=True, grads=True, adam=False, step=step, tile0=step % nb)
+            self._launch(step, 1, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS)
+            return
         self._train_head(step, 1, _lib.NM_F_GRADS | (_lib.NM_F_BNSTATS if bn_stats else 0))
 
     def losses(self) -> torch.Tensor:

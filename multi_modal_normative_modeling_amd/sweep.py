@@ -250,7 +250,8 @@ def evaluate_regression(y_true: np.ndarray, y_pred: np.ndarray) -> Dict[str, flo
 
 def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[int], n_folds: int, epochs: int, device,
                          out_dir=None, modalities: Sequence[str] = prep.HCP_MODALITIES, combine: str = "gpoe",
-                         lr: float = 1e-4, lambda_reg: float = 1.0):
+                         lr: float = 1e-4, lambda_reg: float = 1.0, hidden: Sequence[int] = workload.HIDDEN,
+                         latent: int = workload.LATENT):
     """The whole of multimodal_kfold_train_cvae_supervised_regression.py:52-192 for the given folds, all folds
     training concurrently: cVAE_multimodal_regression on RobustScaler-ed ROI tables with the two raw covariates
     (AGE, PTGENDER) and the FI target; FI prediction on the held-out fold (fold_{k}_pred.npy / _true.npy and
@@ -269,7 +270,7 @@ def run_regression_folds(cohort: prep.SyntheticCohort, folds_to_run: Sequence[in
             sc.append((center, scale))
         scalers.append(sc)
         tables = [Table(x, cov_all[tr], device) for x in xs]
-        spec = ModelSpec([t.D for t in tables], list(workload.HIDDEN), workload.LATENT, 2, True, "regression")
+        spec = ModelSpec([t.D for t in tables], list(hidden), int(latent), 2, True, "regression")
         j = Job(spec, tables, combine=combine, lr=lr, seed=1000 * k, init_seed=42 + k, loss_cap=8)
         j.reg_lambda = float(lambda_reg)
         j.set_fi(cohort.fi[tr].astype(np.float32))
@@ -626,15 +627,16 @@ def main_regression(argv=None, _runner=None):
     ap.add_argument("-BaseLR", "--base_learning_rate", dest="base_learning_rate", type=float, default=1e-4)
     _driver_common(ap)
     args = ap.parse_args(argv)
-    if list(args.hz_para_list) != list(workload.HIDDEN) + [workload.LATENT]:
-        raise ValueError("the regression driver is built for -H 110 110 10 (workload.HIDDEN / LATENT)")
+    if len(args.hz_para_list) < 2:
+        raise ValueError("-H takes the hidden widths followed by the latent size (the script's hz_para_list)")
     cohort = _cohort_from_args(args)
     mods = prep.datasets_name(args.dataset_resourse, args.procedure)
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     out_dir = None if args.out_dir is None else Path(args.out_dir) / args.dataset_resourse / "regression_outputs"
     runner = _runner or run_regression_folds
     res = runner(cohort, _my_folds(args), args.n_splits, args.epochs, device, out_dir=out_dir, modalities=mods,
-                 combine=args.combine.lower(), lr=args.base_learning_rate)
+                 combine=args.combine.lower(), lr=args.base_learning_rate, hidden=list(args.hz_para_list[:-1]),
+                 latent=int(args.hz_para_list[-1]))
     for r in res:
         print("[regression] " + "  ".join(f"{k} {v:.5g}" if isinstance(v, float) else f"{k} {v}" for k, v in r.items()), flush=True)
     return res

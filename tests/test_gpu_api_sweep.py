@@ -252,6 +252,9 @@ def test_regression_and_endtoend_command_lines_one_gpu():
         out = f"{d}/HCPimage/regression_outputs"
         assert np.load(f"{out}/fold_3_pred.npy").shape == (64, 1)
         assert pd.read_csv(f"{out}/deviation_fold_0_{prep.EARLY_FUSION}_roiwise.csv").shape == (320, 1 + 3 * 379)
+        # the regression model at an -H list beyond the fused tile: trunk on the general-shape path, three launches per step
+        res = sweep.main_regression(["-P", "SE-gPoE", "-E", "1", "-K", "5", "--folds", "2", "--subjects", "320", "-H", "200", "200", "10"])
+        assert len(res) == 1 and np.isfinite([res[0]["RMSE"], res[0]["final_mse"], res[0]["final_total"]]).all()
         res = sweep.main_endtoend(["-E", "2", "-K", "5", "--folds", "1", "--subjects", "320", "-Dropout", "0.2", "--out-dir", d])
         assert len(res) == 1 and res[0]["fold"] == 1 and np.isfinite(res[0]["final_ce"]) and 0.0 <= res[0]["accuracy"] <= 1.0
         assert pd.read_csv(f"{d}/HCPimage/endtoend_metrics_rank0.csv").shape[0] == 1
@@ -373,7 +376,8 @@ def test_regression_model_matches_reference():
     assert ok, worst
 
 
-@pytest.mark.parametrize("dims,hidden,B", [([150, 90, 131], [48, 32], 200), ([379, 379, 379], [110, 110], 256)])
+@pytest.mark.parametrize("dims,hidden,B", [([150, 90, 131], [48, 32], 200), ([379, 379, 379], [110, 110], 256),
+                                           ([150, 90, 131], [300, 160], 200)])      # trunk on the general-shape path: three launches
 def test_regression_head_multichunk_vs_oracle(dims, hidden, B):
     """The regression model at sizes whose residual spans several 64-column chunks per modality with ragged last chunks
     (and a ragged batch), and at the full 3 x 379 shape of the regression script: prediction, MSE, every regressor
@@ -1336,6 +1340,49 @@ def test_endtoend_training_with_256_wide_classifier_matches_oracle_trajectory(fu
             opt.step(Pr, {k: leaves[k].grad for k in names})
             row = job.loss_log[s].cpu()
             assert abs(float(row[13]) - float(ol["classification_loss"])) <= 1e-2 * abs(float(ol["classification_loss"])) + 1e-4, s
+    finally:
+        R.set_operand_rounding("fp32")
+    sd = job.state_dict()
+    for k in names:
+        assert float((sd[k] - Pr[k]).abs().max()) <= 2.0 * lr * 2 + 1e-6, k
+
+
+def test_regression_training_on_a_wide_trunk_matches_oracle_trajectory():
+    """cVAE_multimodal_regression with hidden widths beyond the fused tile: the trunk on the general-shape path, the regressor in
+    its own kernel, three launches per step (JobSet.train_regression) -- residual chunk images out of the trunk's forward, the
+    head's d MSE / d x_hat image into its backward.  Two Adam steps against the oracle's trajectory."""
+    dims, hidden, Z, cdim, B = [150, 90, 131], [200, 144], 10, 2, 200
+    spec = nm.ModelSpec(dims, hidden, Z, cdim, True, "regression")
+    assert spec.wide
+    P = nm.ParamLayout(spec).init_reference_rule(9)
+    g = torch.Generator().manual_seed(19)
+    xs = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.rand(B, cdim, generator=g)
+    fi = torch.randn(B, generator=g) * 0.5 + 1.0
+    eps = torch.randn(2, 256, Z, generator=g)
+    lr = 1e-3
+    job = nm.Job(spec, [nm.Table(x, c, DEV) for x in xs], combine="gpoe", state=P, lr=lr, loss_cap=4)
+    job.reg_lambda = 0.7
+    job.set_fi(fi.numpy())
+    job.set_eps(eps)
+    js = nm.JobSet([job])
+    js.train_regression(2)
+    torch.cuda.synchronize()
+    js.assert_finite()
+    rs = R.Spec(dims, hidden, Z, cdim, True, kind="regression")
+    Pr = {k: v.clone() for k, v in P.items()}
+    names = list(R.param_names(rs))
+    opt = R.Adam(Pr, names, lr=lr)
+    R.set_operand_rounding("bf16")
+    try:
+        for s in range(2):
+            leaves = {k: v.clone().requires_grad_(True) for k, v in Pr.items()}
+            fwd = R.forward_regression(leaves, rs, xs, [c] * 3, "gpoe", eps[s, :B])
+            lo = R.loss_regression(rs, xs, fwd, fi.reshape(B, 1), lambda_reg=0.7)
+            lo["total"].backward()
+            opt.step(Pr, {k: leaves[k].grad for k in names})
+            row = job.loss_log[s].cpu()
+            assert abs(float(row[12]) - float(lo["regression"])) <= 1e-2 * abs(float(lo["regression"])) + 1e-4, s
     finally:
         R.set_operand_rounding("fp32")
     sd = job.state_dict()

@@ -107,7 +107,7 @@ def test_random_shape_fused_adam_steps(seed):
 @pytest.mark.parametrize("seed", range(200, 206))
 def test_random_shape_head_models(seed):
     """Regression and end-to-end models at random shapes (residual widths that straddle chunk and modality
-    boundaries, 0-3 classifier blocks of random width, 2-4 classes, ragged batches): losses and every gradient
+    boundaries, 1-3 classifier blocks of random width up to 512, 2-4 classes, ragged batches): losses and every gradient
     against the oracle with the kernels' operand rounding."""
     import multi_modal_normative_modeling_amd as nm
     from oracle import cvae_ref as R
@@ -161,6 +161,8 @@ def test_random_shape_head_models(seed):
     # ---- end-to-end ----
     n_layers = int(rng.integers(1, 4))
     layers = [int(rng.integers(4, 129)) for _ in range(n_layers)]
+    if seed % 2:                                   # odd seeds: one block wider than 128 (the head in 128-column tiles, <= 512)
+        layers[seed % n_layers] += 128 * (1 + seed % 3)
     ncls = int(rng.integers(2, 5))
     c7 = torch.rand(B, 7, generator=g)
     labels = torch.randint(0, ncls, (B,), generator=g)

@@ -223,8 +223,10 @@ def test_regression_and_endtoend_entries_parse_the_reference_flags(tmp_path):
     finally:
         del os.environ["RANK"], os.environ["WORLD_SIZE"]
     assert seen["reg"][1] == [1, 3] and seen["reg"][4]["modalities"] == prep.HCP_MODALITIES
+    sweep.main_regression(["-H", "300", "300", "30", "--subjects", "64"], _runner=reg)     # any hz_para_list: hidden widths + latent
+    assert seen["reg"][4]["hidden"] == [300, 300] and seen["reg"][4]["latent"] == 30
     with pytest.raises(ValueError):
-        sweep.main_regression(["-H", "64", "64", "10", "--subjects", "64"], _runner=reg)
+        sweep.main_regression(["-H", "64", "--subjects", "64"], _runner=reg)
 
     def e2e(cohort, folds, n_splits, epochs, device, **kw):
         seen["e2e"] = (list(folds), epochs, kw)
