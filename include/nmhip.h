@@ -238,7 +238,7 @@ int64_t nm_workspace_bytes(const nm_job_t* job_host);
 
 /* Byte offset, inside one tile's workspace, of the per-expert posterior statistics the fused kernels leave there:
  * what = 0 the means mu_m, 1 the log variances, fp32 [step parity][expert][256][Z rounded to 16] (the reference returns
- * the stacked means as 'qz_xs', cVAE.py:1845); negative: the job keeps none (general-shape path). */
+ * the stacked means as 'qz_xs', cVAE.py:1845); general-shape jobs: [expert][256][Z rounded to 16] (no step parity). */
 int64_t nm_workspace_offset(const nm_job_t* job_host, int what);
 
 /* Validate shapes against the kernel's limits. 0 ok, negative = which limit. */

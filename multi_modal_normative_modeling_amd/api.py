@@ -591,7 +591,7 @@ class mvtCAE(cVAE_multimodal):
         out = super().forward_multimodal(xes, cs, self._kernel_combine(combine))
         # 'qz_xs': the stacked per-expert means [M, B, Z] (cVAE.py:1845) -- the fused kernels leave them in the job's workspace
         j = self._job
-        off = int(_lib.load().nm_workspace_offset(C.byref(j.struct()), 0)) if not self.spec.wide else -1
+        off = int(_lib.load().nm_workspace_offset(C.byref(j.struct()), 0))
         if off >= 0:
             M, Z, Zs, B = self.spec.M, self.spec.latent, (self.spec.latent + 15) // 16 * 16, int(out["mu_multimodal"].shape[0])
             raw = j._ws[off: off + M * _lib.NM_BATCH * Zs * 4].view(torch.float32).view(M, _lib.NM_BATCH, Zs)

@@ -1330,7 +1330,7 @@ const char* nm_status_string(int status) {
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
     case -18: return "out_kind must be 0 or 1, 0 <= n_private <= Z, and a private latent needs an encoder per decoder";
-    case -19: return "general-shape path (wide): cVAE / cVAE_multimodal and the trunks of the end-to-end / regression models only (no DMVAE-family or mvtCAE switches)";
+    case -19: return "general-shape path (wide): cVAE / cVAE_multimodal / mmJSD / mvtCAE (experts x latent <= 256) and the trunks of the end-to-end / regression models; no DMVAE-family switches";
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -20: return "row-split launch: the job uses a switch that needs the whole batch in one workgroup, or lacks gpart / workspace tiles";
@@ -1359,8 +1359,10 @@ int nm_validate_job(const nm_job_t* j) {
     if (j->Z < 1 || j->Z > NM_WIDE_MAX_LATENT) return -5;
     // (the heads of the end-to-end and the regression model run as their own kernels, nm_head_classifier /
     //  nm_head_regression, on any trunk)
-    if (j->out_kind != 0 || j->n_private != 0 || j->tc_weight != 0.f || j->w_off >= 0 || j->combine == NM_COMBINE_POE2V)
-      return -19;
+    // (mvtCAE's switches -- ProductOfExperts2 on variances, the variance floor, the total-correlation term -- are served; its
+    //  log-sum-exps sit in 256 floats of LDS)
+    if (j->out_kind != 0 || j->n_private != 0 || j->w_off >= 0) return -19;
+    if (j->tc_weight != 0.f && (j->M_enc > 0 ? j->M_enc : j->M) * j->Z > 256) return -19;
   } else {
   for (int i = 0; i < j->L; ++i)
     if (j->H[i] < 1 || j->H[i] > NM_MAX_WIDTH) return -4;
@@ -1446,7 +1448,11 @@ int nm_sync_shadow(const nm_job_t* jobs_dev, int n_jobs, void* stream) {
 /* Where a tile's workspace keeps the experts' statistics after a launch of the fused kernels: byte offset of
  * mu_m (what = 0) / logvar_m (what = 1), fp32 [step parity][expert][256][Z rounded to 16]; < 0: none (general-shape jobs). */
 int64_t nm_workspace_offset(const nm_job_t* j, int what) {
-  if (!j || j->wide || what < 0 || what > 1) return -1;
+  if (!j || what < 0 || what > 1) return -1;
+  if (j->wide) {                                   // (general-shape jobs: [expert][256][Z rounded to 16], no step parity)
+    const WideWs ww = wide_ws_layout(j);
+    return what == 0 ? ww.mu_m : ww.lv_m;
+  }
   const WsLayout w = ws_layout(j->M, j->L, j->Z);
   return what == 0 ? w.mu_m : w.lv_m;
 }

@@ -79,8 +79,8 @@ class ModelSpec:
             raise ValueError(f"hidden widths must be 1..{_lib.NM_WIDE_MAX_WIDTH}, got {list(self.hidden)}")
         if not (1 <= self.latent <= _lib.NM_WIDE_MAX_LATENT):
             raise ValueError(f"latent_dim must be 1..{_lib.NM_WIDE_MAX_LATENT}, got {self.latent}")
-        if self.wide and self.kind not in ("single", "multimodal", "endtoend", "regression"):
-            # (the DMVAE family and mvtCAE run on the fused kernel only: DESIGN.md section 6)
+        if self.wide and self.kind not in ("single", "multimodal", "endtoend", "regression", "mvtcae"):
+            # (the DMVAE family runs on the fused kernel only: DESIGN.md section 6)
             raise ValueError(f"model kind '{self.kind}' is limited to hidden widths <= {_lib.NM_MAX_WIDTH}, latent_dim <= "
                              f"{_lib.NM_MAX_LATENT} and latent_dim + c_dim <= {_lib.NM_MAX_WIDTH}; got hidden {list(self.hidden)}, "
                              f"latent {self.latent}, c_dim {self.net_c_dim}")

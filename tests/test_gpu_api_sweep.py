@@ -854,6 +854,49 @@ def test_dm_family_matches_reference(name, cls):
     assert [p.shape for p in preds] == [(g.B, d) for d in g.dims] and devs[0].shape == (g.B,)
 
 
+@pytest.mark.parametrize("combine", ["poe", "gpoe", "mopoe"])
+def test_mvtcae_on_the_general_shape_path_vs_oracle(combine):
+    """mvtCAE (cVAE.py:1754-1893) at hidden widths beyond the fused tile ([300, 160], latent 30): ProductOfExperts2 on
+    variances, the 1e-6 floor and the total-correlation term on the general-shape path -- the four loss terms, the joint
+    posterior, the per-expert means (`qz_xs`) and every gradient against the oracle with bf16 GEMM operands."""
+    dims, hidden, Z, cdim, B = [60, 45, 70], [300, 160], 30, 5, 200
+    torch.manual_seed(13)
+    model = nm.mvtCAE(dims, hidden, Z, cdim, learning_rate=1e-4, modalities=3, non_linear=True)
+    assert model.spec.wide
+    model.to(DEV)
+    g = torch.Generator().manual_seed(29)
+    xes = [torch.randn(B, d, generator=g) for d in dims]
+    c = torch.nn.functional.one_hot(torch.randint(0, cdim, (B,), generator=g), cdim).long()
+    eps = torch.randn(B, Z, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model._eps_override = eps
+    fwd = model.forward_multimodal([x.to(DEV) for x in xes], [c.to(DEV)] * 3, combine)
+    loss = model.loss_function_multimodal(xes, fwd)
+    model.optimizer1.zero_grad()
+    loss["total"].backward()
+    got = {n: p.grad.cpu() for n, p in model._named_views()}
+    spec = R.Spec(dims, hidden, Z, cdim)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        f16 = R.mvt_forward(leaves, spec, xes, [c] * 3, combine, eps)
+        l16 = R.mvt_loss(spec, xes, f16)
+        l16["total"].sum().backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    assert abs(float(loss["ll"]) - float(l16["ll"].sum())) <= 2e-3 * abs(float(l16["ll"].sum()))
+    assert abs(float(loss["tc"]) - float(l16["tc"].sum())) <= 5e-3 * abs(float(l16["tc"].sum())) + 1e-4
+    assert abs(float(loss["kl"]) - float(l16["kl"].sum())) <= 2e-2 * abs(float(l16["kl"].sum())) + 1e-3
+    assert abs(float(loss["total"]) - float(l16["total"].sum())) <= 2e-2 * abs(float(l16["total"].sum())) + 2e-3
+    assert rel_err(fwd["mu_multimodal"].cpu(), f16["mu"].detach()) < 3e-2
+    assert fwd["qz_xs"] is not None and tuple(fwd["qz_xs"].shape) == (3, B, Z)
+    for k, v in leaves.items():
+        if v.grad is None or float(v.grad.norm()) < 1e-12:
+            continue
+        a, r = got[k].flatten().float(), v.grad.flatten()
+        assert float((a - r).norm()) <= 6e-2 * float(r.norm()) + 1e-9, (k, float((a - r).norm() / r.norm()))
+
+
 @pytest.mark.parametrize("name", ["mvtcae3_poe", "mvtcae3_gpoe", "mvtcae3_mopoe"])
 def test_mvtcae_matches_reference(name):
     """mvtCAE of the baseline zoo (cVAE.py:1754-1893) through its reference-named class: the four loss terms of every

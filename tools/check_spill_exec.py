@@ -65,7 +65,7 @@ LIMITS = {
     "nm_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 540},
     "nm_devpass_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 64, "vgpr_count": 128},
     "nm_rs_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 540},
-    "nm_wide_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 340},
+    "nm_wide_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 400},
     "nm_head_step_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 580},
     "nm_reghead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 16},
     "nm_clshead_kernel": {"vgpr_spill_count": 0, "private_segment_fixed_size": 0, "sgpr_spill_count": 140},   # (+ the tiled head)
