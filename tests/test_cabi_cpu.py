@@ -108,9 +108,24 @@ def test_validate_job_limits(lib):
         j.wsh = None                                                # ... and the wide path needs no shadow images
         assert lib.nm_validate_job(C.byref(j)) == 0
         assert lib.nm_workspace_bytes(C.byref(j)) > 0
+    # what the general-shape path serves: the DMVAE family's switches stay on the fused kernel; mvtCAE's total correlation
+    # needs experts x latent <= 256 (its log-sum-exps sit in 256 floats of LDS); the regression head is its own kernel
+    for field, val in (("n_private", 2), ("out_kind", 1), ("w_off", 0)):
+        j = _probe(H=(300, 300), Z=30)
+        j.wide, j.w_off = 1, -1
+        setattr(j, field, val)
+        assert lib.nm_validate_job(C.byref(j)) == -19, field
+    j = _probe(H=(300, 300), Z=30, M=3)
+    j.wide, j.w_off, j.tc_weight = 1, -1, 3e-4
+    assert lib.nm_validate_job(C.byref(j)) == 0
+    j = _probe(H=(300, 300), Z=100, M=3)
+    j.wide, j.w_off, j.tc_weight = 1, -1, 3e-4
+    assert lib.nm_validate_job(C.byref(j)) == -19
     j = _probe(H=(300, 300), Z=30)
     j.wide, j.reg_head, j.w_off = 1, 1, -1
-    assert lib.nm_validate_job(C.byref(j)) == -19                   # head models stay on the fused kernel
+    assert lib.nm_validate_job(C.byref(j)) == -11                   # (regression head: its own buffers are checked as ever)
+    n = lib.nm_fill_shadow(C.byref(j))                              # ... and its first-layer images are the job's only shadow
+    assert 0 < n < 1 << 20 and j.reg_s > 0 and j.mod[0].enc_s[0] == 0 and j.mod[0].out_s == 0
     assert lib.nm_validate_job(C.byref(_probe(H=(5000, 10)))) == -4
 
 
@@ -192,7 +207,12 @@ def test_spec_limits_raise():
         nm.ParamLayout(nm.ModelSpec([10], [5000], 5, 2))
     with pytest.raises(ValueError):
         nm.ParamLayout(nm.ModelSpec([10], [20], 129, 2))
-    with pytest.raises(ValueError):                                           # head models stay on the fused kernel's shapes
-        nm.ParamLayout(nm.ModelSpec([10, 10], [200], 5, 2, True, "regression"))
+    nm.ParamLayout(nm.ModelSpec([10, 10], [200], 5, 2, True, "regression"))   # regression / mvtCAE: general-shape path too
+    nm.ParamLayout(nm.ModelSpec([10, 10], [200], 5, 2, True, "mvtcae"))
+    nm.ParamLayout(nm.ModelSpec([10, 10], [20], 5, 2, True, "endtoend", (256, 128, 64), 2))    # classifier blocks up to 512 wide
+    with pytest.raises(ValueError):
+        nm.ParamLayout(nm.ModelSpec([10, 10], [20], 5, 2, True, "endtoend", (1024, 64), 2))
+    with pytest.raises(ValueError):                                           # the DMVAE family stays on the fused kernel's shapes
+        nm.ParamLayout(nm.ModelSpec([10, 10], [200, 100], 5, 2, True, "dmvae"))
     with pytest.raises(ValueError):
         nm.ParamLayout(nm.ModelSpec([10] * 5, [20], 5, 2))
