@@ -142,7 +142,8 @@ typedef struct nm_job {
                              z | c | 1 is built once per step and reused by the other decoders            */
   int32_t wide;           /* 1: a shape beyond the fused kernel's tile (hidden width > NM_MAX_WIDTH, latent > NM_MAX_LATENT or
                              latent + c_dim > NM_MAX_WIDTH): runs through nm_launch_wide (layers cut into 128-column blocks,
-                             activations in the workspace, no shadow images); plain cVAE / cVAE_multimodal models only */
+                             activations in the workspace, no shadow images but a regression head's first layer); every model
+                             class (mvtCAE: experts x latent <= 256); head models train as three launches per step there */
   int32_t loss_cap;       /* rows of loss_log; step s writes row s % loss_cap            */
   int32_t eps_cap;        /* steps held by eps; step s reads block s % eps_cap           */
   float   lr, beta1, beta2, adam_eps;

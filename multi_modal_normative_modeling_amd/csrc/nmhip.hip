@@ -1330,7 +1330,7 @@ const char* nm_status_string(int status) {
     case -7: return "table pitch: Kx must be a multiple of 32 and >= D + C + 1, x_pitch a multiple of 4 and >= D, Cz a multiple of 8 and >= C + 1";
     case -14: return "n_rows, loss_cap and eps_cap must be >= 1";
     case -18: return "out_kind must be 0 or 1, 0 <= n_private <= Z, and a private latent needs an encoder per decoder";
-    case -19: return "general-shape path (wide): cVAE / cVAE_multimodal / mmJSD / mvtCAE (experts x latent <= 256) and the trunks of the end-to-end / regression models; no DMVAE-family switches";
+    case -19: return "general-shape path (wide): mvtCAE's total correlation needs experts x latent <= 256";
     case -17: return "input preparation: 1 <= rows <= NM_PREP_MAX_ROWS, at least one source / column / bin";
     case -16: return "split launch: jobs x parts exceeds the number of CUs (the parts of a model wait for each other and must all be resident)";
     case -20: return "row-split launch: the job uses a switch that needs the whole batch in one workgroup, or lacks gpart / workspace tiles";
@@ -1361,7 +1361,7 @@ int nm_validate_job(const nm_job_t* j) {
     //  nm_head_regression, on any trunk)
     // (mvtCAE's switches -- ProductOfExperts2 on variances, the variance floor, the total-correlation term -- are served; its
     //  log-sum-exps sit in 256 floats of LDS)
-    if (j->out_kind != 0 || j->n_private != 0 || j->w_off >= 0) return -19;
+    // (so are the DMVAE family's: private latents, sigmoid output, learnable loss weights)
     if (j->tc_weight != 0.f && (j->M_enc > 0 ? j->M_enc : j->M) * j->Z > 256) return -19;
   } else {
   for (int i = 0; i < j->L; ++i)

@@ -79,11 +79,9 @@ class ModelSpec:
             raise ValueError(f"hidden widths must be 1..{_lib.NM_WIDE_MAX_WIDTH}, got {list(self.hidden)}")
         if not (1 <= self.latent <= _lib.NM_WIDE_MAX_LATENT):
             raise ValueError(f"latent_dim must be 1..{_lib.NM_WIDE_MAX_LATENT}, got {self.latent}")
-        if self.wide and self.kind not in ("single", "multimodal", "endtoend", "regression", "mvtcae"):
-            # (the DMVAE family runs on the fused kernel only: DESIGN.md section 6)
-            raise ValueError(f"model kind '{self.kind}' is limited to hidden widths <= {_lib.NM_MAX_WIDTH}, latent_dim <= "
-                             f"{_lib.NM_MAX_LATENT} and latent_dim + c_dim <= {_lib.NM_MAX_WIDTH}; got hidden {list(self.hidden)}, "
-                             f"latent {self.latent}, c_dim {self.net_c_dim}")
+        if self.wide and self.kind == "mvtcae" and self.M * self.latent > 256:
+            # (its total-correlation term keeps experts x latent log-sum-exps in 256 floats of LDS: nm_validate_job -19)
+            raise ValueError(f"mvtCAE beyond the fused kernel's tile needs modalities x latent_dim <= 256, got {self.M} x {self.latent}")
         if self.is_dm and len(self.hidden) != 2:
             raise ValueError("the DMVAE family has exactly two hidden layers (hidden_dims[0], hidden_dims[1])")
         if len(self.classifier_layers) > _lib.NM_MAX_CLS or any(w < 1 or w > _lib.NM_MAX_CLS_WIDTH for w in self.classifier_layers):

@@ -108,13 +108,13 @@ def test_validate_job_limits(lib):
         j.wsh = None                                                # ... and the wide path needs no shadow images
         assert lib.nm_validate_job(C.byref(j)) == 0
         assert lib.nm_workspace_bytes(C.byref(j)) > 0
-    # what the general-shape path serves: the DMVAE family's switches stay on the fused kernel; mvtCAE's total correlation
-    # needs experts x latent <= 256 (its log-sum-exps sit in 256 floats of LDS); the regression head is its own kernel
-    for field, val in (("n_private", 2), ("out_kind", 1), ("w_off", 0)):
+    # what the general-shape path serves: the DMVAE family's switches too; mvtCAE's total correlation needs
+    # experts x latent <= 256 (its log-sum-exps sit in 256 floats of LDS); the regression head is its own kernel
+    for field, val in (("n_private", 2), ("w_off", 0)):
         j = _probe(H=(300, 300), Z=30)
         j.wide, j.w_off = 1, -1
         setattr(j, field, val)
-        assert lib.nm_validate_job(C.byref(j)) == -19, field
+        assert lib.nm_validate_job(C.byref(j)) == 0, field
     j = _probe(H=(300, 300), Z=30, M=3)
     j.wide, j.w_off, j.tc_weight = 1, -1, 3e-4
     assert lib.nm_validate_job(C.byref(j)) == 0
@@ -212,7 +212,8 @@ def test_spec_limits_raise():
     nm.ParamLayout(nm.ModelSpec([10, 10], [20], 5, 2, True, "endtoend", (256, 128, 64), 2))    # classifier blocks up to 512 wide
     with pytest.raises(ValueError):
         nm.ParamLayout(nm.ModelSpec([10, 10], [20], 5, 2, True, "endtoend", (1024, 64), 2))
-    with pytest.raises(ValueError):                                           # the DMVAE family stays on the fused kernel's shapes
-        nm.ParamLayout(nm.ModelSpec([10, 10], [200, 100], 5, 2, True, "dmvae"))
+    nm.ParamLayout(nm.ModelSpec([10, 10], [200, 100], 5, 2, True, "dmvae"))   # ... and the DMVAE family
+    with pytest.raises(ValueError):                                           # mvtCAE there: experts x latent <= 256
+        nm.ParamLayout(nm.ModelSpec([10, 10, 10], [200, 100], 100, 2, True, "mvtcae"))
     with pytest.raises(ValueError):
         nm.ParamLayout(nm.ModelSpec([10] * 5, [20], 5, 2))

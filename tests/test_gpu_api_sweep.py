@@ -854,6 +854,55 @@ def test_dm_family_matches_reference(name, cls):
     assert [p.shape for p in preds] == [(g.B, d) for d in g.dims] and devs[0].shape == (g.B,)
 
 
+@pytest.mark.parametrize("cls,cdim", [("DMVAE", 4), ("WeightedDMVAE", 4), ("mmVAEPlus", 4), ("DMVAE", 29)])
+def test_dm_family_on_the_general_shape_path_vs_oracle(cls, cdim):
+    """DMVAE / WeightedDMVAE / mmVAEPlus (cVAE.py:1491-1747, 1895-2002) at hidden widths beyond the fused tile ([300, 160],
+    latent 12): private / shared latent columns, sigmoid output, the learnable loss weights -- on the general-shape path.
+    Losses, the shared posterior, reconstructions and every gradient against the oracle with bf16 GEMM operands; c_dim 29 >=
+    latent is the shape the scripts run (every latent column private, KL = 0)."""
+    dims, hidden, Z, B = [60, 45, 70], [300, 160], 12, 200
+    torch.manual_seed(17)
+    model = getattr(nm, cls)(dims, hidden, Z, cdim, learning_rate=1e-4, modalities=3, non_linear=True)
+    assert model.spec.wide
+    model.to(DEV)
+    g = torch.Generator().manual_seed(31)
+    xes = [torch.rand(B, d, generator=g) for d in dims]
+    eps = torch.randn(B, Z, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    if cls == "WeightedDMVAE":                       # unequal weights, so that each one's own gradient and scaling is seen
+        sd0["weights"] = torch.tensor([0.8, 1.1, 1.3])
+        model.load_state_dict(sd0)
+        model.to(DEV)
+    model._eps_override = eps
+    fwd = model.forward_multimodal([x.to(DEV) for x in xes], None, "poe")
+    loss = model.loss_function_multimodal(xes, fwd)
+    model.optimizer1.zero_grad()
+    loss["total"].backward()
+    got = {n: p.grad.cpu() for n, p in model._named_views()}
+    spec = R.DmSpec(dims, hidden, Z, cdim, cls)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    R.set_operand_rounding("bf16")
+    try:
+        f16 = R.dm_forward(leaves, spec, xes, eps)
+        l16 = R.dm_loss(leaves, spec, xes, f16)
+        l16["total"].backward()
+    finally:
+        R.set_operand_rounding("fp32")
+    assert abs(float(loss["ll"]) - float(l16["ll"])) <= 2e-3 * abs(float(l16["ll"]))
+    assert abs(float(loss["kl"]) - float(l16["kl"])) <= 2e-2 * abs(float(l16["kl"])) + 1e-6
+    assert abs(float(loss["total"]) - float(l16["total"])) <= 2e-3 * abs(float(l16["total"]))
+    if spec.latent > spec.n_private:
+        assert rel_err(fwd["mu_c"].cpu(), f16["mu_c"].detach()) < 3e-2
+    for m in range(3):
+        assert rel_err(fwd["x_recons"][m].cpu(), f16["x_recons"][m].detach()) < 2e-2
+    for k, v in leaves.items():
+        if v.grad is None or float(v.grad.norm()) < 1e-12:
+            assert k not in got or float(got[k].norm()) < 1e-9, k
+            continue
+        a, r = got[k].flatten().float(), v.grad.flatten()
+        assert float((a - r).norm()) <= 6e-2 * float(r.norm()) + 1e-9, (k, float((a - r).norm() / r.norm()))
+
+
 @pytest.mark.parametrize("combine", ["poe", "gpoe", "mopoe"])
 def test_mvtcae_on_the_general_shape_path_vs_oracle(combine):
     """mvtCAE (cVAE.py:1754-1893) at hidden widths beyond the fused tile ([300, 160], latent 30): ProductOfExperts2 on
