@@ -121,7 +121,7 @@ def test_forward_loss_and_grads(name):
         if float(r32.abs().max()) == 0.0:                # e.g. alpha when the combiner ignores it
             assert float(a.abs().max()) == 0.0, k
             continue
-        assert rel_l2(a, r16) < 3e-2, (k, "bf16-oracle", rel_l2(a, r16))
+        assert rel_l2(a, r16) < 5e-3, (k, "bf16-oracle", rel_l2(a, r16))      # (measured <= 4e-4 on every case)
         assert rel_l2(a, r32) < 0.15, (k, "fp32", rel_l2(a, r32))
         if a.numel() >= 8:
             cos = float(torch.nn.functional.cosine_similarity(a, r32, dim=0))
@@ -169,6 +169,15 @@ def test_adam_trajectory(name):
         n_tot = sum(v.numel() for v in P16.values())
         n_off = sum(int(((sd16[k] - P16[k]).abs() > 0.05 * lr).sum()) for k in P16)
         assert n_off <= 0.02 * (s + 1) * n_tot + 2, ("bf16-oracle", s, n_off, n_tot)
+        # Adam's moments against the oracle that does the kernel's arithmetic (bf16 GEMM operands, fp32 everything else):
+        # measured <= 1.3e-3 relative L2 on every tensor of every case and step (the bounds against the fp32 reference
+        # below are 0.15 / 0.30 -- that distance is the operand rounding, not the kernel)
+        m16, v16 = job.adam_dicts()
+        for k in opt16.m:
+            if float(opt16.m[k].abs().max()) == 0.0 or opt16.m[k].numel() < 8:
+                continue
+            assert rel_l2(m16[k], opt16.m[k]) < 5e-3, ("bf16-oracle exp_avg", k, s)
+            assert rel_l2(v16[k], opt16.v[k]) < 1e-2, ("bf16-oracle exp_avg_sq", k, s)
         row = job.loss_log[0].cpu()
         ref = g.z[f"loss{s}"]
         assert abs(float(row[2]) - ref[2]) <= 1e-4 * abs(ref[2]), (s, float(row[2]), ref[2])
