@@ -13,6 +13,7 @@ folds = prep.kfold_indices(len(cohort.iid), 5, 42)
 xs, c = prep.fold_train_tables(cohort, prep.HCP_MODALITIES, folds[0][0])
 tabs = [nm.Table(x, c, DEV) for x in xs]
 for name, mods, hidden, Z, jobs in (("fused  SE 3x379 [110,110]/10", 3, [110, 110], 10, 256),
+                                    ("wide   SE 3x379 [110,110]/70", 3, [110, 110], 70, 256),
                                     ("wide   SE 3x379 [110,110]/100", 3, [110, 110], 100, 256),
                                     ("wide   SE 3x379 [300,300]/30", 3, [300, 300], 30, 256),
                                     ("wide   SM 379 [1024,512,256]/32", 1, [1024, 512, 256], 32, 256),
