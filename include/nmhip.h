@@ -272,7 +272,8 @@ int nm_launch_wide(const nm_job_t* jobs_dev, int n_jobs, int step0, int steps_pe
  * partials complete, Adam sweep complete); the k fp32 partial gradients are summed in slice order, so results are bitwise
  * reproducible run to run and agree with nm_launch to fp32 summation order (not bit for bit).  Every job of the launch:
  * M modalities, all with an encoder (M_enc == 0 or M), k workspace tiles, gpart / gpart_stride set, nm_rowsplit_ok() == 0.
- * flags: NM_F_BACKWARD with NM_F_ADAM (training) or NM_F_GRADS (n_steps == 1: the summed gradients go to job.grads).
+ * flags: NM_F_BACKWARD with NM_F_ADAM (training) or NM_F_GRADS (n_steps == 1: the summed gradients go to job.grads);
+ * NM_F_EXPORT: every slice stores its rows of the exports (reconstructions, latent, deviations), as nm_launch does.
  * spread_us > 0 (launches of >= 16 steps): job j starts j / n_jobs of spread_us microseconds late, so that the models of a
  * full chip do not run their Adam sweeps -- the step's burst of memory traffic -- at the same moment (pass ~one step's time).
  * helpers (0..60): extra workgroups per (model, modality) that take no part in the step itself and only share its Adam

@@ -123,11 +123,13 @@ class _Base(nn.Module):
             vc = (key, self.layout.nat_views(self._flat.data))
             self.__dict__["_view_cache"] = vc
             self.__dict__["_nat_grads"] = None
+            self.__dict__["_grad_views"] = None
         return vc[1]
 
     def _build_tree(self):
         self.__dict__["_view_cache"] = None
         self.__dict__["_nat_grads"] = None
+        self.__dict__["_grad_views"] = None
         v = {k: nn.Parameter(t, requires_grad=False) for k, t in self._views().items()}
         s, L = self.spec, len(self.spec.hidden)
         if s.is_dm:                                 # encoder_list.{m}.fc1 ... / decoder_list.{m}.fc_out (cVAE.py:1453-1479)
@@ -188,6 +190,7 @@ class _Base(nn.Module):
             self._flat.data = self._flat.data.to(dev)
             self.__dict__["_view_cache"] = None
             self.__dict__["_nat_grads"] = None
+            self.__dict__["_grad_views"] = None
             self._build_tree()
             self._device = dev
             self._job = None
@@ -254,6 +257,8 @@ class _Base(nn.Module):
             j.step = 0
             j.touch()
         if (flags & _lib.NM_F_BACKWARD) and nt == 1 and self.spec.kind == "multimodal" and self._js.split_parts() > 1:
+            # (the row-split launch would cut this kernel from ~210 to ~105 us, measured -- and leave the step where it is: the
+            #  loop through this class costs ~0.45 ms of HOST time per step, tools/facade_host_time.py)
             # One workgroup per modality (bit-identical, ~2.3x faster).  Its workgroups wait for each other; if a hand-off times
             # out (another stream or process holding CUs) they leave the launch BEFORE the loss row is written, and what sits in
             # loss_log / grads is the previous call's.  Reading the error words here would stall the stream every step, so the
@@ -297,6 +302,15 @@ class _Base(nn.Module):
             if name != "_flat":
                 out.append((name, p))
         return out
+
+    def zero_grad(self, set_to_none: bool = True):
+        """nn.Module.zero_grad walks named_parameters() -- 0.15 ms for this module tree, a third of a step of the reference's
+        loop through this class.  The only gradients this module ever holds are the views _assign_grads set: drop those."""
+        gv = self.__dict__.get("_grad_views")
+        if gv is None or not set_to_none:
+            return super().zero_grad(set_to_none)
+        for p, _ in gv:
+            p.grad = None
 
     def reparameterise(self, mu, logvar):
         return mu + torch.randn_like(mu) * torch.exp(0.5 * logvar)          # cVAE.py:418-421

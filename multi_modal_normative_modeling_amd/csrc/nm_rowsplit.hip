@@ -473,7 +473,7 @@ int nm_launch_rowsplit(const nm_job_t* jobs_dev, int n_jobs, int M, int k, int h
   if (wgs > cus) return -16;            // the workgroups of a model wait for each other: all must be resident
   hipStream_t st = (hipStream_t)stream;
   nm_sync_reset(jobs_dev, n_jobs, stream);
-  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_TRACE | NM_F_FAULT_INJECT | NM_F_PROFILE);
+  flags &= (NM_F_BACKWARD | NM_F_ADAM | NM_F_GRADS | NM_F_EXPORT | NM_F_TRACE | NM_F_FAULT_INJECT | NM_F_PROFILE);
   if (spread_us < 0 || n_steps < 16) spread_us = 0;          // (an offset is pure cost at the end of a short launch)
   hipError_t e;
   if (k == 2) {

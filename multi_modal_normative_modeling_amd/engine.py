@@ -648,7 +648,7 @@ class JobSet:
         s = self.jobs[0].step if step is None else step
         flags = _lib.NM_F_BACKWARD | _lib.NM_F_GRADS | (_lib.NM_F_EXPORT if export else 0)
         if rowsplit > 1:
-            self._launch_rowsplit(rowsplit, s, 1, _lib.NM_F_BACKWARD | _lib.NM_F_GRADS, helpers)
+            self._launch_rowsplit(rowsplit, s, 1, flags, helpers)
         elif split:
             ptr = self._upload(1)
             _lib.check(self.lib.nm_launch_split(ptr, len(self.jobs), len(self.jobs[0].kmods), int(s), 1, int(flags),

@@ -45,12 +45,23 @@ def test_rowsplit_gradients_and_loss(name, k):
     83-row tail leaves one slice ragged and two empty."""
     g = Golden(name)
     whole = make_job(g, 0)
-    nm.JobSet([whole]).grads(0, export=False)
+    whole.enable_exports()
+    nm.JobSet([whole]).grads(0, export=True)
     job = make_job(g, 0)
+    job.enable_exports()
     js = nm.JobSet([job])
-    js.grads(0, rowsplit=k)
+    js.grads(0, rowsplit=k)                                   # (NM_F_EXPORT on: every slice stores its rows of the exports)
     js.check_split_errors(block=True)
     torch.cuda.synchronize()
+    # exports: per row the same arithmetic as the whole-batch launch -- reconstructions, squared errors, per-subject
+    # deviations, joint posterior and the draw (the eager classes' backward runs row-split and reads them)
+    B = g.B
+    for m in range(g.M):
+        assert torch.equal(job.out_loc[m][:B], whole.out_loc[m][:B]), m
+        assert torch.equal(job.out_sqerr[m][:B], whole.out_sqerr[m][:B]), m
+        assert torch.allclose(job.out_rowdev[m][:B], whole.out_rowdev[m][:B], rtol=2e-6, atol=1e-9), m
+    assert torch.equal(job.out_mu[:B], whole.out_mu[:B]) and torch.equal(job.out_logvar[:B], whole.out_logvar[:B])
+    assert torch.equal(job.out_z[:B], whole.out_z[:B])
     _, loss16, grads16 = oracle_in_mode(g, "bf16")
     _, _, grads32 = oracle_in_mode(g, "fp32")
     row, wrow = job.loss_log[0].cpu(), whole.loss_log[0].cpu()
