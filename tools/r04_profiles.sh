@@ -14,6 +14,7 @@ step all_configs bash -c "python tools/bench_configs.py | grep -v amdgpu > $O/al
 step trace256 bash -c "python tools/trace_profile.py --jobs 256 --procedure SE-gPoE > $O/wave_trace_256_jobs_SE.txt"
 step trace1 bash -c "python tools/trace_profile.py --jobs 1 --procedure SE-gPoE > $O/wave_trace_single_job_SE.txt"
 step small bash -c "python tools/bench_small.py --trace --modes wg,split,rs2h0,rs2,rs4h0,rs4 | grep -v amdgpu > $O/small_sweeps_rowsplit.txt"; grep models $O/small_sweeps_rowsplit.txt
+step smallprof bash -c "cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/prof_small_$TAG -- python3 \$GRAFT_REPO_ROOT/tools/bench_small.py --modes rs4 > /dev/null"; find gpurun_out/prof_small_$TAG -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_small_sweeps_rowsplit.csv \; ; rm -rf gpurun_out/prof_small_$TAG; head -3 $O/kernel_stats_small_sweeps_rowsplit.csv | cut -c1-200
 step dev bash -c "python tools/bench_deviation.py | grep -v amdgpu > $O/deviation_pass_nm_devpass.txt"; tail -1 $O/deviation_pass_nm_devpass.txt
 step devg bash -c "python tools/bench_deviation.py --general | grep -v amdgpu > $O/deviation_pass_general_kernel.txt"; tail -1 $O/deviation_pass_general_kernel.txt
 step devprof bash -c "cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/prof_dev_$TAG -- python3 \$GRAFT_REPO_ROOT/tools/bench_deviation.py > /dev/null"; find gpurun_out/prof_dev_$TAG -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_deviation_pass.csv \; ; rm -rf gpurun_out/prof_dev_$TAG; head -3 $O/kernel_stats_deviation_pass.csv | cut -c1-200
