@@ -195,7 +195,23 @@ def test_rowsplit_many_models_pick_and_refusal():
     torch.cuda.synchronize()
     assert torch.equal(jobs[3].params.cpu(), alone.params.cpu())
     assert not torch.equal(jobs[3].params.cpu(), jobs[4].params.cpu())
-    assert nm.JobSet([make_job(g, 0) for _ in range(5)]).rowsplit_k() == 4
+    five = nm.JobSet([make_job(g, 0) for _ in range(5)])
+    assert five.rowsplit_k() == 4 and five.rowsplit_helpers(4) == 12          # 15 groups -> 16 x (4 + 12) = 256 workgroups
+    # five models with the idle CUs lent to their sweeps == the same five without helpers == a model alone, bit for bit
+    for i, j in enumerate(five.jobs):
+        j.seed = i
+        j.set_eps(None)
+    five.train(3)
+    five.check_split_errors(block=True)
+    bare = [make_job(g, 0) for _ in range(5)]
+    for i, j in enumerate(bare):
+        j.seed = i
+        j.set_eps(None)
+    nm.JobSet(bare).train(3, rowsplit=4, helpers=0)
+    torch.cuda.synchronize()
+    for a, b in zip(five.jobs, bare):
+        assert torch.equal(a.params.cpu(), b.params.cpu()) and torch.equal(a.adam_v.cpu(), b.adam_v.cpu())
+    assert torch.equal(five.jobs[3].params.cpu(), alone.params.cpu())
     assert nm.JobSet([make_job(g, 0) for _ in range(40)]).rowsplit_k() == 2     # 120 groups x 2 = 240
     big = nm.JobSet([make_job(g, 0) for _ in range(96)])
     assert big.rowsplit_k() == 1
